@@ -1,0 +1,254 @@
+"""Synthetic grids, forcing and berg populations for the BASELINE.json configs.
+
+All gridded arrays are numpy float64 of shape (nj, ni), C-contiguous, indexed [j - jsd, i - isd]: the
+same bytes as the Fortran array f(isd:ied, jsd:jed) the reference owns (icebergs_framework.F90:950-1004).
+The halo of the static grid is filled the way ice_bergs_framework_init does for a non-cyclic domain:
+corner lon/lat by linear extrapolation (icebergs_framework.F90:1069-1094).
+
+The population generator reproduces the reference's calving-class tables: mass / thickness /
+mass_scaling per class (icebergs_framework.F90:787-790) and width = sqrt(M / (LoW * rho * T)),
+length = LoW * width (icebergs_framework.F90:1540-1541).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import types as T
+
+INITIAL_MASS = np.array([8.8e7, 4.1e8, 3.3e9, 1.8e10, 3.8e10, 7.5e10, 1.2e11, 2.2e11, 3.9e11, 7.4e11])
+INITIAL_THICKNESS = np.array([40., 67., 133., 175., 250., 250., 250., 250., 250., 250.])
+MASS_SCALING = np.array([2000., 200., 50., 20., 10., 5., 2., 1., 1., 1.])
+INITIAL_MASS_N = np.array([4.58e8, 3.61e9, 1.22e10, 2.91e10, 5.09e10, 7.34e10, 1.15e11, 1.65e11, 2.94e11, 5.59e11])
+LOW_RATIO = 1.5
+RHO_BERGS = 850.0
+HALO = 4  # icebergs_framework.F90:686
+
+
+def default_params():
+    """Namelist defaults (icebergs_framework.F90:686-822) + pinned FMS constants."""
+    p = T.Params()
+    p.pi, p.omega, p.HLF = 3.14159265358979323846, 7.292e-5, 3.34e5
+    p.dt, p.current_year, p.current_yearday = 1800.0, 1, 0.0
+    p.Rearth, p.rho_bergs, p.lat_ref = 6360000.0, 850.0, 0.0
+    p.cdrag_grounding, p.h_to_init_grounding, p.ocean_drag_scale = 0.0, 100.0, 1.0
+    p.speed_limit = p.sicn_shift = p.bergy_bit_erosion_fraction = p.tip_parameter = 0.0
+    p.grounding_fraction = p.clipping_depth = p.coastal_drift = p.tidal_drift = 0.0
+    p.initial_orientation, p.melt_cutoff = 0.0, -1.0
+    p.cdrag_icebergs, p.utide_icebergs, p.ustar_icebergs_bg, p.Gamma_T_3EQ = 1.5e-3, 0.0, 0.001, 0.022
+    p.fl_youngs, p.fl_strength, p.new_berg_from_fl_bits_mass_thres = 1.0e7, 250.0, 1.0e12
+    for k in range(10):
+        p.initial_mass_s[k] = INITIAL_MASS[k]
+        p.initial_mass_n[k] = INITIAL_MASS_N[k]
+    p.Runge_not_Verlet = 1
+    p.old_interp_flds_order = 1
+    p.old_bug_bilin = 1
+    p.use_operator_splitting = 1
+    p.add_weight_to_ocean = 1
+    p.use_old_spreading = 1
+    p.allow_bergs_to_roll = 1
+    p.Use_three_equation_model = 1
+    p.const_gamma = 1
+    p.use_roundoff_fix = 1
+    p.fl_style = T.ENUMS["KID_FL_STYLE_NEW_BERGS"]
+    p.fl_bits_erosion_to_bergy_bits = 1
+    p.displace_fl_bergs = 1
+    return p
+
+
+def _desc(ni_c, nj_c, latlon, regular, Lx):
+    d = T.GridDesc()
+    d.isc, d.iec, d.jsc, d.jec = 1, ni_c, 1, nj_c
+    d.isd, d.ied, d.jsd, d.jed = 1 - HALO, ni_c + HALO, 1 - HALO, nj_c + HALO
+    d.grid_is_latlon, d.grid_is_regular, d.Lx = int(latlon), int(regular), float(Lx)
+    return d
+
+
+def _ij(d):
+    i = np.arange(d.isd, d.ied + 1, dtype=np.float64)[None, :]
+    j = np.arange(d.jsd, d.jed + 1, dtype=np.float64)[:, None]
+    return i, j
+
+
+def zeros(d):
+    return np.zeros((d.jed - d.jsd + 1, d.ied - d.isd + 1))
+
+
+def cartesian_grid(ni=20, nj=20, gridres=1000.0, Lx=-1.0, depth=1000.0):
+    """The stand-alone driver's synthetic Cartesian grid (driver/icebergs_driver.F90:274-286)."""
+    d = _desc(ni, nj, latlon=False, regular=True, Lx=Lx)
+    i, j = _ij(d)
+    one = zeros(d) + 1.0
+    st = {"lon": gridres * i * one, "lat": gridres * j * one}
+    st["lonc"] = st["lon"] - 0.5 * gridres
+    st["latc"] = st["lat"] - 0.5 * gridres
+    st["dx"] = one * gridres
+    st["dy"] = one * gridres
+    st["area"] = one * gridres * gridres
+    st["msk"] = one.copy()
+    st["cos"] = one.copy()
+    st["sin"] = zeros(d)
+    st["ocean_depth"] = one * depth
+    return {"desc": d, "static": st, "forcing": {k: zeros(d) for k in T.FORCING_NAMES}}
+
+
+def c1_forcing(grid, P=20000.0):
+    """SURVEY 8d config C1 analytic forcing; velocities on B-grid corners, tracers at cell centres."""
+    st, f = grid["static"], grid["forcing"]
+    x, y, xc, yc = st["lon"], st["lat"], st["lonc"], st["latc"]
+    w = 2.0 * np.pi / P
+    f["uo"][:] = 0.2 * np.sin(w * y)
+    f["vo"][:] = 0.1 * np.cos(w * x)
+    f["ua"][:] = 5.0
+    f["va"][:] = -3.0
+    f["ssh"][:] = 0.05 * np.sin(w * xc) * np.sin(w * yc)
+    f["sst"][:] = -1.0 + 3.0 * np.sin(w * xc) * np.cos(w * yc)
+    f["sss"][:] = -1.0  # icebergs.F90:5357 when the coupler passes no salinity
+    return grid
+
+
+def latlon_grid(ni=360, nj=200, lon0=0.0, dlon=1.0, lat0=-80.0, dlat=0.8, Rearth=6.36e6, continents=False):
+    """SURVEY 8d config C2 grid: corners lon=i, lat=-80+0.8 j; calc_xiyj path (grid_is_regular=F)."""
+    d = _desc(ni, nj, latlon=True, regular=False, Lx=360.0)
+    i, j = _ij(d)
+    one = zeros(d) + 1.0
+    rad = np.pi / 180.0
+    st = {"lon": (lon0 + dlon * i) * one, "lat": (lat0 + dlat * j) * one}
+    st["lonc"] = st["lon"] - 0.5 * dlon
+    st["latc"] = st["lat"] - 0.5 * dlat
+    st["dx"] = Rearth * np.cos(st["lat"] * rad) * (dlon * rad)
+    st["dy"] = one * Rearth * (dlat * rad)
+    st["area"] = Rearth ** 2 * (dlon * rad) * np.abs(np.sin(st["lat"] * rad) - np.sin((st["lat"] - dlat) * rad))
+    msk = one.copy()
+    if continents:  # "blocky continents": three rectangles of land, to exercise the coast bounce
+        for (i0, i1, j0, j1) in ((60, 110, 60, 150), (200, 230, 30, 90), (280, 330, 110, 170)):
+            msk[(j >= j0) & (j <= j1) & (i >= i0) & (i <= i1) & (one > 0)] = 0.0
+    st["msk"] = msk
+    st["cos"] = one.copy()
+    st["sin"] = zeros(d)
+    st["ocean_depth"] = one * 4000.0
+    return {"desc": d, "static": st, "forcing": {k: zeros(d) for k in T.FORCING_NAMES}}
+
+
+def c2_forcing(grid):
+    """zonal jet, weak meridional flow, westerly wind band, SST; no sea ice."""
+    st, f = grid["static"], grid["forcing"]
+    rad = np.pi / 180.0
+    lon, lat, lonc, latc = st["lon"], st["lat"], st["lonc"], st["latc"]
+    f["uo"][:] = 0.3 * np.cos(3.0 * lat * rad)
+    f["vo"][:] = 0.05 * np.sin(2.0 * lon * rad)
+    f["ua"][:] = 8.0 * np.exp(-((np.abs(lat) - 50.0) / 15.0) ** 2)
+    f["va"][:] = 1.0 * np.sin(lon * rad)
+    f["ssh"][:] = 0.3 * np.sin(2.0 * lonc * rad) * np.cos(2.0 * latc * rad)
+    f["sst"][:] = np.maximum(-1.8, 10.0 * np.cos(latc * rad) * (1.0 + 0.2 * np.sin(3.0 * lonc * rad)) - 4.0)
+    f["sss"][:] = -1.0
+    land = st["msk"] < 0.5  # icebergs.F90:5364-5372 scrub
+    for k in ("ua", "va", "uo", "vo", "ui", "vi", "sst", "sss", "cn", "hi"):
+        f[k][land] = 0.0
+    return grid
+
+
+def empty_bergs(n):
+    b = {name: np.zeros(n) for name in T.BERG_F64_NAMES}
+    for name in T.BERG_I32_NAMES:
+        b[name] = np.zeros(n, dtype=np.int32)
+    b["alive"][:] = 1
+    b["id"] = np.arange(1, n + 1, dtype=np.int64)
+    return b
+
+
+def _fill_classes(b, klass, jitter=None):
+    M = INITIAL_MASS[klass].copy()
+    Tk = INITIAL_THICKNESS[klass].copy()
+    if jitter is not None:
+        M *= jitter
+    W = np.sqrt(M / (LOW_RATIO * RHO_BERGS * Tk))
+    b["mass"][:] = M
+    b["thickness"][:] = Tk
+    b["width"][:] = W
+    b["length"][:] = LOW_RATIO * W
+    b["mass_scaling"][:] = MASS_SCALING[klass]
+    b["start_mass"][:] = M
+    return b
+
+
+def sort_reference_order(b):
+    """cells j-outer / i-inner (icebergs.F90:7106), `inorder` inside a cell
+    (icebergs_framework.F90:4318-4359)."""
+    order = np.lexsort((b["start_lat"], b["start_lon"], b["start_mass"], b["start_day"], b["start_year"],
+                        b["ine"], b["jne"]))
+    for k in list(b.keys()):
+        b[k] = np.ascontiguousarray(b[k][order])
+    return b
+
+
+def place_bergs(grid, n, seed, i_range, j_range, klass=None, wet_only=True):
+    """Uniform random positions inside cells [i_range] x [j_range]; (xi, yj) from the cell's own corners."""
+    d, st = grid["desc"], grid["static"]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    b = empty_bergs(n)
+    ine = rng.integers(i_range[0], i_range[1] + 1, size=n)
+    jne = rng.integers(j_range[0], j_range[1] + 1, size=n)
+    if wet_only:
+        for _ in range(64):
+            bad = st["msk"][jne - d.jsd, ine - d.isd] < 0.5
+            if not bad.any():
+                break
+            ine[bad] = rng.integers(i_range[0], i_range[1] + 1, size=int(bad.sum()))
+            jne[bad] = rng.integers(j_range[0], j_range[1] + 1, size=int(bad.sum()))
+    xi = rng.uniform(0.02, 0.98, size=n)
+    yj = rng.uniform(0.02, 0.98, size=n)
+    lon0 = st["lon"][jne - d.jsd, ine - 1 - d.isd]
+    lon1 = st["lon"][jne - d.jsd, ine - d.isd]
+    lat0 = st["lat"][jne - 1 - d.jsd, ine - d.isd]
+    lat1 = st["lat"][jne - d.jsd, ine - d.isd]
+    b["lon"][:] = lon0 + xi * (lon1 - lon0)
+    b["lat"][:] = lat0 + yj * (lat1 - lat0)
+    # in-cell coordinates as pos_within_cell would return them for a rectangular cell
+    b["xi"][:] = (b["lon"] - lon0) / (lon1 - lon0)
+    b["yj"][:] = (b["lat"] - lat0) / (lat1 - lat0)
+    b["ine"][:] = ine
+    b["jne"][:] = jne
+    if klass is None:
+        klass = rng.integers(0, 10, size=n)
+    _fill_classes(b, klass)
+    b["start_lon"][:] = b["lon"]
+    b["start_lat"][:] = b["lat"]
+    b["start_year"][:] = 0
+    b["start_day"][:] = 1.0e-6 * np.arange(n)  # makes the `inorder` sort total
+    b["lon_old"][:] = b["lon"]
+    b["lat_old"][:] = b["lat"]
+    return sort_reference_order(b)
+
+
+def config_c1(n=10, seed=1):
+    """BASELINE config 1: 10 point bergs, 20x20 f-plane Cartesian grid, analytic forcing."""
+    grid = c1_forcing(cartesian_grid(20, 20, 1000.0, Lx=-1.0))
+    p = default_params()
+    p.dt, p.lat_ref, p.use_f_plane = 600.0, -70.0, 1
+    b = place_bergs(grid, n, seed, (4, 17), (4, 17), klass=np.arange(n) % 10)
+    return grid, p, b
+
+
+def config_c2(n=1_000_000, seed=2, continents=False):
+    """BASELINE config 2: n bergs (random mass classes), 360x200 lat-lon grid, drag+Coriolis+melt."""
+    grid = c2_forcing(latlon_grid(continents=continents))
+    p = default_params()
+    p.dt = 1800.0
+    # |lat| < 75 -> j in [7, 193]; keep clear of the periodic seam (berg migration is out of scope, SURVEY #13)
+    b = place_bergs(grid, n, seed, (6, 355), (8, 192))
+    return grid, p, b
+
+
+def set_diag_all(p):
+    p.diag_mask = (1 << 20) - 1
+    return p
+
+
+def copy_bergs(b):
+    return {k: v.copy() for k, v in b.items()}
+
+
+def params_copy(p):
+    q = T.Params()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(T.Params))
+    return q

@@ -1,0 +1,219 @@
+/* kid_types.h -- plain-data interface types of the KID (Kinematic Iceberg Dynamics) evolve-loop boundary.
+ *
+ * These are interface types only (no algorithm).  They describe, as flat C structs, the pieces of the
+ * reference's Fortran derived types that the per-berg evolve loop reads and writes:
+ *   - type icebergs_gridded   /root/reference/src/icebergs_framework.F90:112-229  -> kid_grid_desc + field enums
+ *   - type iceberg            /root/reference/src/icebergs_framework.F90:290-359  -> kid_berg_soa (structure of arrays)
+ *   - scalar members of type icebergs and the module switches
+ *                             /root/reference/src/icebergs_framework.F90:28-64, 421-616 -> kid_params
+ *
+ * All arrays are column-major exactly as Fortran owns them: a gridded field f(isd:ied,jsd:jed) is
+ * passed as a pointer to f(isd,jsd); element (i,j) lives at [(i-isd) + (j-jsd)*(ied-isd+1)].
+ * "real" in the reference is fp64 (the FMS build promotes with -r8), integers are int32 except berg ids.
+ */
+#ifndef KID_TYPES_H
+#define KID_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- grid descriptor: index ranges + geometry switches (FW:112-140, FW:748-749, FW:712) ---- */
+typedef struct kid_grid_desc {
+  int32_t isd, ied, jsd, jed;   /* data domain (with halo)   */
+  int32_t isc, iec, jsc, jec;   /* computational domain      */
+  int32_t grid_is_latlon;       /* FW:748 */
+  int32_t grid_is_regular;      /* FW:749 */
+  double  Lx;                   /* FW:712 zonal period; <=0 means not periodic */
+} kid_grid_desc;
+
+/* ---- static grid fields, grd%* after ice_bergs_framework_init (FW:1021-1094) ---- */
+enum {
+  KID_G_LON = 0,   /* grd%lon  : NE-corner longitude of cell (i,j)  */
+  KID_G_LAT,       /* grd%lat  */
+  KID_G_LONC,      /* grd%lonc : cell-centre longitude              */
+  KID_G_LATC,
+  KID_G_DX, KID_G_DY, KID_G_AREA, KID_G_MSK, KID_G_COS, KID_G_SIN, KID_G_OCEAN_DEPTH,
+  KID_NGRID_STATIC
+};
+
+/* ---- forcing fields, grd%* after the ingest block of icebergs_run (IB:5236-5383) ---- */
+enum {
+  KID_F_UO = 0, KID_F_VO, KID_F_UI, KID_F_VI, KID_F_UA, KID_F_VA,
+  KID_F_SSH, KID_F_SST, KID_F_SSS, KID_F_CN, KID_F_HI,
+  KID_NFORCING
+};
+
+/* ---- per-berg fp64 fields (type iceberg, FW:294-343) ---- */
+enum {
+  KID_B_LON = 0, KID_B_LAT, KID_B_UVEL, KID_B_VVEL,
+  KID_B_MASS, KID_B_THICKNESS, KID_B_WIDTH, KID_B_LENGTH,
+  KID_B_AXN, KID_B_AYN, KID_B_BXN, KID_B_BYN,
+  KID_B_UVEL_PREV, KID_B_VVEL_PREV, KID_B_UVEL_OLD, KID_B_VVEL_OLD, KID_B_LON_OLD, KID_B_LAT_OLD,
+  KID_B_START_LON, KID_B_START_LAT, KID_B_START_DAY, KID_B_START_MASS,
+  KID_B_MASS_SCALING, KID_B_MASS_OF_BITS, KID_B_MASS_OF_FL_BITS, KID_B_MASS_OF_FL_BERGY_BITS,
+  KID_B_FL_K, KID_B_HEAT_DENSITY, KID_B_HALO_BERG, KID_B_STATIC_BERG,
+  KID_B_XI, KID_B_YJ,
+  /* environment as seen by the berg (FW:331-343) */
+  KID_B_UO, KID_B_VO, KID_B_UI, KID_B_VI, KID_B_UA, KID_B_VA,
+  KID_B_SSH_X, KID_B_SSH_Y, KID_B_SST, KID_B_SSS, KID_B_CN, KID_B_HI, KID_B_OD,
+  KID_NB_F64
+};
+/* ---- per-berg int32 fields ---- */
+enum { KID_BI_INE = 0, KID_BI_JNE, KID_BI_START_YEAR, KID_BI_N_BONDS, KID_BI_ALIVE, KID_NB_I32 };
+
+/* Structure of arrays: one contiguous array of length n per field.  A NULL pointer on upload means
+ * "all zero"; on download it means "do not copy this field back". */
+typedef struct kid_berg_soa {
+  int64_t  n;
+  double  *f64[KID_NB_F64];
+  int32_t *i32[KID_NB_I32];
+  int64_t *id;               /* FW:325 integer(kind=8) :: id */
+} kid_berg_soa;
+
+/* ---- per-cell accumulators written by the hot path (zeroed at IB:5125-5156) ---- */
+enum {
+  KID_A_FLOATING_MELT = 0, /* IB:3117 */
+  KID_A_BERG_MELT,         /* IB:3133 */
+  KID_A_CALVING_HFLX,      /* IB:3129 (increment only; the caller adds the masked coupler input, IB:5207) */
+  KID_A_BERGY_SRC,         /* IB:3136 */
+  KID_A_BERGY_MELT,        /* IB:3139 */
+  KID_A_FL_BITS_MELT,      /* IB:3142 */
+  KID_A_FL_BITS_SRC,       /* IB:3287, IB:2642 */
+  KID_A_MELT_BUOY, KID_A_MELT_EROS, KID_A_MELT_CONV,             /* IB:3154-3165 */
+  KID_A_MELT_BUOY_FL, KID_A_MELT_EROS_FL, KID_A_MELT_CONV_FL,    /* IB:3167-3198 */
+  KID_A_FL_PARENT_MELT, KID_A_FL_CHILD_MELT,                     /* IB:3146-3153, 3183-3186 */
+  KID_A_MASS, KID_A_BERGY_MASS, KID_A_FL_BITS_MASS, KID_A_FL_BERGY_BITS_MASS, /* IB:5050-5070 */
+  KID_A_VIRTUAL_AREA, KID_A_U_ICEBERG, KID_A_V_ICEBERG,          /* IB:5026-5058 */
+  KID_A_MASS_ON_OCEAN,                       /* 9 consecutive slots, IB:4088 */
+  KID_A_AREA_ON_OCEAN = KID_A_MASS_ON_OCEAN + 9,
+  KID_A_UVEL_ON_OCEAN = KID_A_AREA_ON_OCEAN + 9,
+  KID_A_VVEL_ON_OCEAN = KID_A_UVEL_ON_OCEAN + 9,
+  KID_A_MELT_BY_CLASS = KID_A_VVEL_ON_OCEAN + 9, /* 10 classes, IB:3125 */
+  KID_NACC = KID_A_MELT_BY_CLASS + 10
+};
+/* ---- derived gridded outputs of create_gridded_icebergs_fields (IB:3390-3489) ---- */
+enum {
+  KID_O_SPREAD_MASS = 0, KID_O_SPREAD_AREA, KID_O_SPREAD_UVEL, KID_O_SPREAD_VVEL, KID_O_USTAR_ICEBERG,
+  KID_NOUT
+};
+/* ---- scalars mutated on `bergs` by the hot path ---- */
+enum {
+  KID_S_NET_HEAT_TO_OCEAN = 0,  /* IB:3130 */
+  KID_S_NBERGS_MELTED,          /* IB:3295 */
+  KID_S_NBERGS_CALVED_FL,       /* IB:2634, IB:3275 */
+  KID_S_NSPEEDING_TICKETS,      /* IB:2314 */
+  KID_S_NBERGS_ALIVE,           /* bookkeeping of the SoA (not in the reference) */
+  KID_S_ERROR_COUNT,            /* bergs that hit a reference FATAL/WARNING path (e.g. IB:3207, FW:6502) */
+  KID_NSCALAR = 8
+};
+
+/* diagnostics that the reference guards with `id_*>0` (diag_manager ids, FW:1567-1673) */
+enum {
+  KID_DIAG_MELT_BY_CLASS  = 1 << 0,  /* IB:3119 */
+  KID_DIAG_FL_PARENT_MELT = 1 << 1,  /* IB:3146 */
+  KID_DIAG_FL_CHILD_MELT  = 1 << 2,
+  KID_DIAG_MELT_BUOY      = 1 << 3,
+  KID_DIAG_MELT_EROS      = 1 << 4,
+  KID_DIAG_MELT_CONV      = 1 << 5,
+  KID_DIAG_MELT_BUOY_FL   = 1 << 6,
+  KID_DIAG_MELT_EROS_FL   = 1 << 7,
+  KID_DIAG_MELT_CONV_FL   = 1 << 8,
+  KID_DIAG_VIRTUAL_AREA   = 1 << 9,  /* IB:5026 */
+  KID_DIAG_MASS           = 1 << 10, /* IB:5051 */
+  KID_DIAG_U_ICEBERG      = 1 << 11,
+  KID_DIAG_V_ICEBERG      = 1 << 12,
+  KID_DIAG_BERGY_MASS     = 1 << 13, /* IB:5061 (also on when add_weight_to_ocean) */
+  KID_DIAG_FL_BITS_MASS   = 1 << 14,
+  KID_DIAG_FL_BERGY_BITS_MASS = 1 << 15,
+  KID_DIAG_SPREAD_UVEL    = 1 << 16, /* IB:3419 */
+  KID_DIAG_SPREAD_VVEL    = 1 << 17,
+  KID_DIAG_SPREAD_AREA    = 1 << 18,
+  KID_DIAG_USTAR_ICEBERG  = 1 << 19  /* IB:3466 */
+};
+
+enum { KID_FL_STYLE_NEW_BERGS = 0, KID_FL_STYLE_FL_BITS = 1 };
+
+/* ---- scalar parameters: namelist icebergs_nml (FW:825-856, defaults FW:686-822) + FMS constants ---- */
+typedef struct kid_params {
+  /* FMS constants_mod values (not in the reference tree; pinned) */
+  double pi, omega, HLF;
+  /* time */
+  double dt;                      /* bergs%dt */
+  int32_t current_year; int32_t pad0;
+  double current_yearday;
+  /* physics scalars */
+  double Rearth;                  /* FW:44  */
+  double rho_bergs;               /* FW:694 */
+  double lat_ref;                 /* FW:709 */
+  double cdrag_grounding;         /* FW:697 */
+  double h_to_init_grounding;     /* FW:698 */
+  double ocean_drag_scale;        /* FW:813 */
+  double speed_limit;             /* FW:726 */
+  double sicn_shift;              /* FW:708 */
+  double bergy_bit_erosion_fraction; /* FW:707 */
+  double tip_parameter;           /* FW:729 */
+  double grounding_fraction;      /* FW:730 */
+  double clipping_depth;          /* FW:227 */
+  double coastal_drift;           /* FW:731 */
+  double tidal_drift;             /* FW:732 (must be 0: the stochastic stream is FMS's) */
+  double initial_orientation;     /* FW:713 */
+  double melt_cutoff;             /* FW:718 */
+  double cdrag_icebergs;          /* FW:716 */
+  double utide_icebergs;          /* FW:714 */
+  double ustar_icebergs_bg;       /* FW:715 */
+  double Gamma_T_3EQ;             /* FW:717 */
+  double fl_youngs;               /* FW:817 */
+  double fl_strength;             /* FW:818 */
+  double new_berg_from_fl_bits_mass_thres; /* FW:822 */
+  double u_override, v_override;  /* FW:710-711 */
+  double initial_mass_s[10];      /* FW:787 */
+  double initial_mass_n[10];      /* FW:793 */
+  /* switches (0/1) */
+  int32_t Runge_not_Verlet;             /* FW:733 */
+  int32_t use_new_predictive_corrective;/* FW:770 */
+  int32_t old_interp_flds_order;        /* FW:1483 (derived) */
+  int32_t old_bug_bilin;                /* FW:40  */
+  int32_t use_f_plane;                  /* FW:747 */
+  int32_t use_operator_splitting;       /* FW:720 */
+  int32_t add_weight_to_ocean;          /* FW:721 */
+  int32_t time_average_weight;          /* FW:723 */
+  int32_t use_old_spreading;            /* FW:778 */
+  int32_t hexagonal_icebergs;           /* FW:753 */
+  int32_t allow_bergs_to_roll;          /* FW:752 */
+  int32_t use_updated_rolling_scheme;   /* FW:738 */
+  int32_t set_melt_rates_to_zero;       /* FW:751 */
+  int32_t use_mixed_melting;            /* FW:734 */
+  int32_t melt_icebergs_as_ice_shelf;   /* FW:743 */
+  int32_t Use_three_equation_model;     /* FW:742 */
+  int32_t use_mixed_layer_salinity_for_thermo; /* FW:740 */
+  int32_t const_gamma;                  /* FW:719 */
+  int32_t apply_thickness_cutoff_to_bergs_melt;   /* FW:737 */
+  int32_t apply_thickness_cutoff_to_gridded_melt; /* FW:736 */
+  int32_t Iceberg_melt_without_decay;   /* FW:744 */
+  int32_t find_melt_using_spread_mass;  /* FW:741 */
+  int32_t override_iceberg_velocities;  /* FW:746 */
+  int32_t iceberg_bonds_on;             /* FW:51  */
+  int32_t internal_bergs_for_drag;      /* FW:735 */
+  int32_t dem;                          /* FW:52  */
+  int32_t mts;                          /* FW:48  */
+  int32_t footloose;                    /* FW:64  */
+  int32_t fl_style;                     /* FW:820 (KID_FL_STYLE_*) */
+  int32_t fl_bits_erosion_to_bergy_bits;/* FW:821 */
+  int32_t displace_fl_bergs;            /* FW:819 */
+  int32_t use_roundoff_fix;             /* FW:37  */
+  int32_t interactive_icebergs_on;      /* FW:771 */
+  int32_t only_interactive_forces;      /* FW:757 */
+  int32_t pass_fields_to_ocean_model;   /* FW:739 */
+  int32_t static_icebergs;              /* FW:756 */
+  int32_t old_bug_rotated_weights;      /* FW:38  */
+  int32_t diag_mask;                    /* KID_DIAG_* : which `id_*>0` guards are on */
+  int32_t pad1[2];
+} kid_params;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KID_TYPES_H */

@@ -1,0 +1,79 @@
+/* kid_oracle.h -- CPU restatement (ORACLE) of the NOAA-GFDL/icebergs per-berg evolve loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ may be imported, linked or executed by the product
+ * (icebergs_amd/): only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * there only as the checker.  See oracle/kid_oracle.c for the pinning status.
+ */
+#ifndef KID_ORACLE_H
+#define KID_ORACLE_H
+#include "../include/kid_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ko_grid {
+  kid_grid_desc d;
+  const double *stat[KID_NGRID_STATIC];   /* static grid fields  */
+  const double *forc[KID_NFORCING];       /* forcing fields      */
+} ko_grid;
+
+/* geometry (icebergs_framework.F90) */
+double ko_modulo(double a, double p);
+double ko_apply_modulo_around_point(double x, double y, double Lx);
+double ko_bilin(const ko_grid *g, const kid_params *p, const double *fld, int i, int j, double xi, double yj);
+int    ko_sum_sign_dot_prod4(double x0, double y0, double x1, double y1, double x2, double y2,
+                             double x3, double y3, double x, double y, double Lx);
+int    ko_sum_sign_dot_prod5(double x0, double y0, double x1, double y1, double x2, double y2,
+                             double x3, double y3, double x4, double y4, double x, double y, double Lx);
+int    ko_is_point_in_cell(const ko_grid *g, double x, double y, int i, int j);
+int    ko_calc_xiyj(double x1, double x2, double x3, double x4, double y1, double y2, double y3, double y4,
+                    double x, double y, double *xi, double *yj, double Lx);
+int    ko_pos_within_cell(const ko_grid *g, const kid_params *p, double x, double y, int i, int j,
+                          double *xi, double *yj, int *err);
+
+/* environment + momentum (icebergs.F90) */
+void ko_interp_flds(const ko_grid *g, const kid_params *p, double x, double y, int i, int j, double xi, double yj,
+                    double env[13]);
+void ko_accel(const ko_grid *g, const kid_params *p, const double bergstate[], int n_bonds,
+              int i, int j, double xi, double yj, double lat, double uvel, double vvel, double uvel0, double vvel0,
+              double dt, double *ax, double *ay, double *axn, double *ayn, double *bxn, double *byn,
+              int64_t *ntickets);
+void ko_adjust_index_and_ground(const ko_grid *g, const kid_params *p, double *lon, double *lat,
+                                int *i, int *j, double *xi, double *yj, int *bounced, int *err);
+
+/* thermodynamics helpers */
+void   ko_rolling(const kid_params *p, double *Tn, double *Wn, double *Ln);
+void   ko_fl_bits_dimensions(const kid_params *p, double thickness, double *L_fl, double *W_fl, double *T_fl);
+double ko_find_basal_melt(const kid_grid_desc *gd, const kid_params *p, double dvo, double lat, double salt,
+                          double temp, int use_three_eq, double thickness);
+
+/* mass spreading geometry */
+void ko_hexagon_into_quadrants(double x0, double y0, double H, double theta, double *Area_hex,
+                               double *Q1, double *Q2, double *Q3, double *Q4);
+int  ko_point_in_triangle(double Ax, double Ay, double Bx, double By, double Cx, double Cy, double qx, double qy);
+void ko_spread_weights(const ko_grid *g, const kid_params *p, int i, int j, double x, double y,
+                       double Area, double static_berg, double w[9], double *I_fraction_used);
+
+/* whole phases over a berg population (SoA in, SoA out, in place) */
+void ko_interp_gridded_fields_to_bergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b);
+void ko_evolve_icebergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *scalars);
+void ko_thermodynamics(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc, double *scalars);
+void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, kid_berg_soa *b,
+                                       double *acc, double *out);
+void ko_footloose_calving(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
+                          double *acc, double *scalars);
+/* One icebergs_run() worth of the hot path (IB:5423-5512), accumulators zeroed first.
+ * acc: KID_NACC fields of (ied-isd+1)*(jed-jsd+1); out: KID_NOUT fields; scalars: KID_NSCALAR. */
+void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
+                 double *acc, double *out, double *scalars);
+/* reference traversal order: permutation sorted by (jne, ine, inorder-key) */
+void ko_reference_order(const kid_berg_soa *b, int64_t *perm);
+
+void ko_default_params(kid_params *p);
+int64_t ko_sizeof(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,137 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE -- never imported by icebergs_amd/).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, ".."))
+from icebergs_amd import types as T  # noqa: E402  (interface types only)
+
+
+class KoGrid(C.Structure):
+    _fields_ = [("d", T.GridDesc),
+                ("stat", C.POINTER(C.c_double) * T.ENUMS["KID_NGRID_STATIC"]),
+                ("forc", C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"])]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def load():
+    so = os.path.join(_HERE, "libkid_oracle.so")
+    if not os.path.exists(so):
+        build()
+    lib = C.CDLL(so)
+    d = C.c_double
+    lib.ko_sizeof.restype = C.c_int64
+    assert lib.ko_sizeof(0) == C.sizeof(T.Params), "kid_params layout mismatch"
+    assert lib.ko_sizeof(1) == C.sizeof(T.GridDesc)
+    assert lib.ko_sizeof(2) == C.sizeof(T.BergSoA)
+    assert lib.ko_sizeof(3) == C.sizeof(KoGrid)
+    lib.ko_modulo.restype = d; lib.ko_modulo.argtypes = [d, d]
+    lib.ko_apply_modulo_around_point.restype = d; lib.ko_apply_modulo_around_point.argtypes = [d, d, d]
+    lib.ko_bilin.restype = d
+    lib.ko_bilin.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(d), C.c_int, C.c_int, d, d]
+    lib.ko_is_point_in_cell.restype = C.c_int
+    lib.ko_is_point_in_cell.argtypes = [C.POINTER(KoGrid), d, d, C.c_int, C.c_int]
+    lib.ko_pos_within_cell.restype = C.c_int
+    lib.ko_pos_within_cell.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), d, d, C.c_int, C.c_int,
+                                       C.POINTER(d), C.POINTER(d), C.POINTER(C.c_int)]
+    lib.ko_calc_xiyj.restype = C.c_int
+    lib.ko_calc_xiyj.argtypes = [d] * 10 + [C.POINTER(d), C.POINTER(d), d]
+    lib.ko_interp_flds.restype = None
+    lib.ko_interp_flds.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), d, d, C.c_int, C.c_int, d, d, C.POINTER(d)]
+    lib.ko_find_basal_melt.restype = d
+    lib.ko_find_basal_melt.argtypes = [C.POINTER(T.GridDesc), C.POINTER(T.Params), d, d, d, d, C.c_int, d]
+    lib.ko_hexagon_into_quadrants.restype = None
+    lib.ko_hexagon_into_quadrants.argtypes = [d, d, d, d] + [C.POINTER(d)] * 5
+    lib.ko_point_in_triangle.restype = C.c_int
+    lib.ko_point_in_triangle.argtypes = [d] * 8
+    lib.ko_rolling.restype = None
+    lib.ko_rolling.argtypes = [C.POINTER(T.Params)] + [C.POINTER(d)] * 3
+    lib.ko_spread_weights.restype = None
+    lib.ko_spread_weights.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.c_int, C.c_int, d, d, d, d,
+                                      C.POINTER(d), C.POINTER(d)]
+    lib.ko_default_params.restype = None
+    lib.ko_default_params.argtypes = [C.POINTER(T.Params)]
+    for name in ("ko_interp_gridded_fields_to_bergs",):
+        getattr(lib, name).restype = None
+        getattr(lib, name).argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA)]
+    lib.ko_evolve_icebergs.restype = None
+    lib.ko_evolve_icebergs.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d)]
+    lib.ko_thermodynamics.restype = None
+    lib.ko_thermodynamics.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
+    lib.ko_create_gridded_icebergs_fields.restype = None
+    lib.ko_create_gridded_icebergs_fields.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
+    lib.ko_footloose_calving.restype = None
+    lib.ko_footloose_calving.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64, C.POINTER(d), C.POINTER(d)]
+    lib.ko_run_step.restype = None
+    lib.ko_run_step.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64,
+                                C.POINTER(d), C.POINTER(d), C.POINTER(d)]
+    lib.ko_reference_order.restype = None
+    lib.ko_reference_order.argtypes = [C.POINTER(T.BergSoA), C.POINTER(C.c_int64)]
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    """Drives the oracle over numpy state: a grid dict (see icebergs_amd.synthetic) and a berg dict."""
+
+    def __init__(self, grid, params):
+        self.lib = load()
+        self.grid = grid
+        self.params = params
+        self.kg = KoGrid()
+        self.kg.d = grid["desc"]
+        self._keep = []
+        for k, name in enumerate(T.GRID_STATIC_NAMES):
+            a = np.ascontiguousarray(grid["static"][name], dtype=np.float64)
+            self._keep.append(a)
+            self.kg.stat[k] = _dp(a)
+        self.set_forcing(grid["forcing"])
+        ni = grid["desc"].ied - grid["desc"].isd + 1
+        nj = grid["desc"].jed - grid["desc"].jsd + 1
+        self.ni, self.nj = ni, nj
+        self.acc = np.zeros((T.NACC, nj, ni))
+        self.out = np.zeros((T.NOUT, nj, ni))
+        self.scalars = np.zeros(T.NSCALAR)
+
+    def set_forcing(self, forcing):
+        self._fkeep = []
+        for k, name in enumerate(T.FORCING_NAMES):
+            a = np.ascontiguousarray(forcing[name], dtype=np.float64)
+            self._fkeep.append(a)
+            self.kg.forc[k] = _dp(a)
+
+    @staticmethod
+    def soa(bergs):
+        s = T.BergSoA()
+        n = len(bergs["lon"])
+        s.n = n
+        for k, name in enumerate(T.BERG_F64_NAMES):
+            a = bergs[name]
+            assert a.dtype == np.float64 and a.flags.c_contiguous and len(a) >= n
+            s.f64[k] = _dp(a)
+        for k, name in enumerate(T.BERG_I32_NAMES):
+            a = bergs[name]
+            assert a.dtype == np.int32 and a.flags.c_contiguous
+            s.i32[k] = a.ctypes.data_as(C.POINTER(C.c_int32))
+        s.id = bergs["id"].ctypes.data_as(C.POINTER(C.c_int64))
+        return s
+
+    def run_step(self, bergs, nsteps=1):
+        s = self.soa(bergs)
+        for _ in range(nsteps):
+            self.lib.ko_run_step(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]),
+                                 _dp(self.acc), _dp(self.out), _dp(self.scalars))
+        return bergs

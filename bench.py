@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- berg-steps/s of the MI355X evolve loop on BASELINE config 2 (configs[1]).
+
+Workload: 1e6 synthetic bergs (random mass classes) per GPU on the 360x200 lat-lon ocean grid, default namelist
+physics (RK4, drag + Coriolis + wave radiation + SSH slope, melt, rolling, rectangular mass spreading), fp64.
+One *step* is one icebergs_run() worth of the hot path over the whole population: device-side forcing prepass,
+accumulator zeroing, the fused per-berg kernel (evolve + thermodynamics + mass spreading), the cross-GPU sum of the
+per-cell accumulators (RCCL all-reduce, N>1 only) and the 9-point gather.  Inputs are resident in HBM before the
+timed region starts.  Weak scaling: every rank owns its own 1e6 bergs (different seeds), the grid is replicated.
+
+Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N>1
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_BERG_STEP = 256.0  # SURVEY.md 8d (config 2): 129 B read + 128 B written of per-berg SoA state
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(nbergs, nsteps):
+    """The CPU oracle (scalar C restatement of the reference loop), 1 core, on a bounded cut of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    from icebergs_amd import synthetic as S
+    grid, p, b = S.config_c2(n=nbergs, seed=2)
+    o = oracle_lib.Oracle(grid, p)
+    o.run_step(b, 1)  # touch everything once
+    t0 = time.perf_counter()
+    o.run_step(b, nsteps)
+    dt = time.perf_counter() - t0
+    return {"value": nbergs * nsteps / dt, "unit": "berg-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d bergs x %d steps of config 2 (same generator, seed 2), oracle/kid_oracle.c -O2, 1 thread, %.1f s"
+                      % (nbergs, nsteps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bergs", type=int, default=1_000_000, help="bergs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-bergs", type=int, default=500_000)
+    ap.add_argument("--cpu-steps", type=int, default=16)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from icebergs_amd import synthetic as S, types as T
+    from icebergs_amd.framework import Icebergs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    # ---- workload: config 2, one shard of `bergs` per rank, replicated grid ----
+    grid, params, bergs = S.config_c2(n=args.bergs, seed=2 + 1000 * rank)
+    ib = Icebergs(grid, params, capacity=args.bergs, device=local_rank)
+    ib.set_stream(torch.cuda.current_stream().cuda_stream)
+    ib.upload_bergs(bergs)
+    # forcing planes resident on the device (as an ocean/ice model on the same GPU would hand them over)
+    forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
+    forcing_ptrs = [t.data_ptr() for t in forcing_dev]
+    # accumulator block in a torch tensor so that RCCL can reduce it in place
+    _, count = ib.accum_device_ptr()
+    acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
+    ib.bind_accum_buffer(acc_t.data_ptr(), count)
+    ncore = T.ENUMS["KID_NACC_CORE"] * ib.ncell
+    acc_core, acc_scal = acc_t[:ncore], acc_t[T.NACC * ib.ncell:]
+
+    def step():
+        ib.set_forcing_device(forcing_ptrs)      # forcing prepass (device-to-device + per-cell records)
+        ib.step_local()                          # zero accumulators + fused per-berg kernel
+        if dist is not None:                     # the one exchange of the path: per-cell sums over xGMI
+            dist.all_reduce(acc_core)
+            dist.all_reduce(acc_scal)
+        ib.step_gather()                         # 9-point gather, ustar, derived planes
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ib.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    berg_ms, launches, _ = ib.profile_get()
+    ib.profile(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_slots, n_alive = ib.num_bergs()
+
+    if rank == 0:
+        total_bergs = args.bergs * world
+        value = total_bergs * args.steps / elapsed
+        kern_ms = berg_ms / max(launches, 1)
+        achieved = ALGO_BYTES_PER_BERG_STEP * args.bergs / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        line = {
+            "metric": "berg_steps_per_sec", "value": value, "unit": "berg-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
+                                   "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s" % args.bergs,
+                       "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
+                       "exchange": "RCCL all-reduce of %d per-cell planes (%.1f MB) per step" % (T.ENUMS["KID_NACC_CORE"], ncore * 8 / 1e6) if world > 1 else "none (1 GPU)",
+                       "bergs_alive_at_end": n_alive},
+            "per_gpu_value": value / world,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "berg_kernel<RK4,old_interp_order,evolve|thermo|spread>",
+                         "kernel_ms_avg": kern_ms, "kernel_launches": launches,
+                         "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_bergs, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ib.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,693 @@
+// kid_device.hpp -- gfx950 device functions of the KID evolve loop (one wavefront lane per berg, fp64, no MFMA).
+//
+// Written for CDNA4 directly: the ocean/atmosphere/ice fields are repacked into 64-byte per-cell records so
+// that one bilinear interpolation of all eight B-grid fields is four 64-byte record loads (two 128-byte
+// lines, shared by the neighbouring lanes of a cell-sorted wave) instead of 32 scattered 8-byte loads, and the
+// per-call grid arithmetic of the reference (sea-surface-slope stencils, ocean_depth+ssh) is hoisted into a
+// per-cell prepass.  Arithmetic that reaches a berg is kept in the reference's operation order; each function
+// cites the reference lines it implements (IB = src/icebergs.F90, FW = src/icebergs_framework.F90).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/kid_types.h"
+
+namespace kid {
+
+// reference module constants, IB:68-80
+constexpr double RHO_ICE = 916.7, RHO_AIR = 1.1, RHO_SEAWATER = 1025.0, GRAVITY = 9.8;
+constexpr double CD_AV = 1.3, CD_AH = 0.0055, CD_WV = 0.9, CD_WH = 0.0012, CD_IV = 0.9;
+
+// B-grid corner record (i,j): everything bilin() reads in interp_flds (IB:4757-4765)
+struct alignas(64) VelRec { double cosr, sinr, uo, vo, ui, vi, ua, va; };
+// A-grid cell record (i,j): PCM tracers (IB:4815-4818), od (IB:4897) and the hoisted slope stencils (IB:4903-4926)
+struct alignas(64) TrcRec { double sst, sss, cn, hi, od, ddx, ddy, msk; };
+// corner geometry + cell area/mask (FW:6325-6332, IB:7945-7975, IB:3114)
+struct alignas(32) GeoRec { double lon, lat, area, msk; };
+
+struct DevGrid {
+  int isd, ied, jsd, jed, isc, iec, jsc, jec, ni, nj;
+  int latlon, regular;
+  double Lx;
+  const VelRec *vel;
+  const TrcRec *trc;
+  const GeoRec *geo;
+  const double *dx, *dy, *ocean_depth, *ssh;
+  __device__ __forceinline__ int idx(int i, int j) const { return (i - isd) + (j - jsd) * ni; }
+};
+
+struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; };
+
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double sign1(double b) { return copysign(1.0, b); }
+
+// Fortran MODULO(a,p), p>0 (FW:6568).  Longitudes handed to it are within one period of the window almost
+// always, where the exact result needs no division; the general case falls back to fmod.
+__device__ __forceinline__ double f_modulo(double a, double p) {
+  if (a >= 0.0) {
+    if (a < p) return a;
+    if (a < 2.0 * p) return a - p;  // exact (Sterbenz)
+  } else if (a > -p) {
+    return a + p;
+  }
+  double r = fmod(a, p);
+  if (r != 0.0 && (r < 0.0)) r += p;
+  return r;
+}
+__device__ __forceinline__ double mod_around(double x, double y, double Lx) {  // FW:6558-6573
+  if (Lx > 0.) {
+    const double lo = y - Lx / 2.;
+    return f_modulo(x - lo, Lx) + lo;
+  }
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// point-in-cell tests, FW:6076-6296
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sum_sign_dot_prod4(double x0, double y0, double x1, double y1, double x2, double y2,
+                                                   double x3, double y3, double x, double y, double Lx) {
+  const double xx = mod_around(x, x0, Lx), xx0 = mod_around(x0, x0, Lx), xx1 = mod_around(x1, x0, Lx);
+  const double xx2 = mod_around(x2, x0, Lx), xx3 = mod_around(x3, x0, Lx);
+  const double l0 = (xx - xx0) * (y1 - y0) - (y - y0) * (xx1 - xx0);
+  const double l1 = (xx - xx1) * (y2 - y1) - (y - y1) * (xx2 - xx1);
+  const double l2 = (xx - xx2) * (y3 - y2) - (y - y2) * (xx3 - xx2);
+  const double l3 = (xx - xx3) * (y0 - y3) - (y - y3) * (xx0 - xx3);
+  // south and east edges belong to the cell, north and west do not (FW:6199-6206)
+  const double p0 = (l0 == 0.) ? -0.5 : sign1(l0), p1 = (l1 == 0.) ? 0.5 : sign1(l1);
+  const double p2 = (l2 == 0.) ? 0.5 : sign1(l2), p3 = (l3 == 0.) ? -0.5 : sign1(l3);
+  return ((fabs(p0) + fabs(p2)) + (fabs(p1) + fabs(p3))) == fabs((p0 + p2) + (p1 + p3));
+}
+__device__ __noinline__ bool sum_sign_dot_prod5(double x0, double y0, double x1, double y1, double x2, double y2,
+                                                double x3, double y3, double x4, double y4, double x, double y, double Lx) {
+  const double xx = mod_around(x, x0, Lx), xx0 = mod_around(x0, x0, Lx), xx1 = mod_around(x1, x0, Lx);
+  const double xx2 = mod_around(x2, x0, Lx), xx3 = mod_around(x3, x0, Lx), xx4 = mod_around(x4, x0, Lx);
+  const double l0 = (xx - xx0) * (y1 - y0) - (y - y0) * (xx1 - xx0);
+  const double l1 = (xx - xx1) * (y2 - y1) - (y - y1) * (xx2 - xx1);
+  const double l2 = (xx - xx2) * (y3 - y2) - (y - y2) * (xx3 - xx2);
+  const double l3 = (xx - xx3) * (y4 - y3) - (y - y3) * (xx4 - xx3);
+  const double l4 = (xx - xx4) * (y0 - y4) - (y - y4) * (xx0 - xx4);
+  const double p0 = (l0 == 0.) ? 0. : sign1(l0), p1 = (l1 == 0.) ? 0. : sign1(l1), p2 = (l2 == 0.) ? 0. : sign1(l2);
+  const double p3 = (l3 == 0.) ? 0. : sign1(l3), p4 = (l4 == 0.) ? 0. : sign1(l4);
+  return (((fabs(p0) + fabs(p2)) + (fabs(p1) + fabs(p3))) + fabs(p4) - fabs(((p0 + p2) + (p1 + p3)) + p4)) < 0.5;
+}
+
+// the four corners of cell (i,j): 00=(i-1,j-1) 10=(i,j-1) 11=(i,j) 01=(i-1,j)
+struct Corners { double lon00, lat00, lon10, lat10, lon11, lat11, lon01, lat01; };
+__device__ __forceinline__ Corners load_corners(const DevGrid &g, int i, int j) {
+  const int c = g.idx(i, j);
+  const GeoRec a = g.geo[c - g.ni - 1], b = g.geo[c - g.ni], d = g.geo[c], e = g.geo[c - 1];
+  return Corners{a.lon, a.lat, b.lon, b.lat, d.lon, d.lat, e.lon, e.lat};
+}
+__device__ __forceinline__ bool cell_in_data_domain(const DevGrid &g, int i, int j) {
+  return !(i - 1 < g.isd || i > g.ied || j - 1 < g.jsd || j > g.jed);
+}
+
+__device__ __forceinline__ bool is_point_in_cell(const DevGrid &g, const Corners &q, double x, double y) {  // FW:6102-6158
+  const double Lx = g.Lx;
+  const double a = mod_around(q.lon00, x, Lx), b = mod_around(q.lon10, x, Lx);
+  const double c = mod_around(q.lon01, x, Lx), d = mod_around(q.lon11, x, Lx);
+  const double xlo = dmin(dmin(dmin(a, b), c), d), xhi = dmax(dmax(dmax(a, b), c), d);
+  const double tol = 0.1;
+  if (x < (xlo - tol) || x > (xhi + tol)) return false;
+  const double ylo = dmin(dmin(dmin(q.lat00, q.lat10), q.lat01), q.lat11);
+  const double yhi = dmax(dmax(dmax(q.lat00, q.lat10), q.lat01), q.lat11);
+  if (y < ylo || y > yhi) return false;
+  if (g.latlon && yhi > 89.999) {  // one corner at the pole: five-sided polygon (cold path)
+    if (q.lat11 > 89.999)
+      return sum_sign_dot_prod5(q.lon00, q.lat00, q.lon10, q.lat10, q.lon10, q.lat11, q.lon01, q.lat11, q.lon01, q.lat01, x, y, Lx);
+    else if (q.lat01 > 89.999)
+      return sum_sign_dot_prod5(q.lon00, q.lat00, q.lon10, q.lat10, q.lon11, q.lat11, q.lon11, q.lat01, q.lon00, q.lat01, x, y, Lx);
+    else if (q.lat00 > 89.999)
+      return sum_sign_dot_prod5(q.lon01, q.lat00, q.lon10, q.lat00, q.lon10, q.lat10, q.lon11, q.lat11, q.lon01, q.lat01, x, y, Lx);
+    else if (q.lat10 > 89.999)
+      return sum_sign_dot_prod5(q.lon00, q.lat00, q.lon00, q.lat10, q.lon11, q.lat10, q.lon11, q.lat11, q.lon01, q.lat01, x, y, Lx);
+  }
+  return sum_sign_dot_prod4(q.lon00, q.lat00, q.lon10, q.lat10, q.lon11, q.lat11, q.lon01, q.lat01, x, y, Lx);
+}
+
+// FW:6439-6534.  Returns false on the reference's FATAL paths.
+__device__ __forceinline__ bool calc_xiyj(double x1, double x2, double x3, double x4, double y1, double y2, double y3, double y4,
+                                          double x, double y, double &xi, double &yj, double Lx) {
+  const double alpha = x2 - x1, delta = y2 - y1, beta = x4 - x1, epsilon = y4 - y1;
+  const double gamma = (x3 - x1) - (alpha + beta), kappa = (y3 - y1) - (delta + epsilon);
+  double a = (kappa * beta - gamma * epsilon);
+  const double dx = mod_around(x, x1, Lx) - x1, dy = y - y1;
+  double b = (delta * beta - alpha * epsilon) - (kappa * dx - gamma * dy);
+  double c = (alpha * dy - delta * dx);
+  bool ok = true;
+  if (fabs(a) > 1.e-12) {
+    const double d = 0.25 * (b * b) - a * c;
+    if (d >= 0.) {
+      const double sd = sqrt(d);
+      const double yy1 = -(0.5 * b + sd) / a, yy2 = -(0.5 * b - sd) / a;
+      yj = (fabs(yy1 - 0.5) < fabs(yy2 - 0.5)) ? yy1 : yy2;
+    } else { ok = false; yj = -999.; }
+  } else {
+    yj = (b != 0.) ? -c / b : 0.;
+  }
+  a = (alpha + gamma * yj);
+  b = (delta + kappa * yj);
+  if (a != 0.) xi = (dx - beta * yj) / a;
+  else if (b != 0.) xi = (dy - epsilon * yj) / b;
+  else {
+    c = (epsilon * alpha - beta * delta) + (epsilon * gamma - beta * kappa) * yj;
+    if (c != 0.) xi = (epsilon * dx - beta * dy) / c; else { ok = false; xi = -999.; }
+  }
+  return ok;
+}
+
+// FW:6299-6436 (debug=.false.).  err is set on the reference's FATAL paths.
+__device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_params &p, double x, double y, int i, int j,
+                                                double &xi, double &yj, int &err) {
+  xi = -999.; yj = -999.;
+  if (!cell_in_data_domain(g, i, j)) return false;
+  const Corners q = load_corners(g, i, j);
+  if (!g.latlon && g.regular) {
+    const double ddx = fabs(q.lon11 - q.lon01), ddy = fabs(q.lat11 - q.lat10);
+    const double x1 = q.lon11 - (ddx / 2), y1 = q.lat11 - (ddy / 2);
+    const double Delta_x = mod_around(x, x1, g.Lx) - x1;
+    xi = ((Delta_x) / ddx) + 0.5;
+    yj = ((y - y1) / ddy) + 0.5;
+  } else if (!g.latlon || dmax(dmax(dmax(q.lat00, q.lat10), q.lat11), q.lat01) < 89.999) {
+    if (!calc_xiyj(q.lon00, q.lon10, q.lon11, q.lon01, q.lat00, q.lat10, q.lat11, q.lat01, x, y, xi, yj, g.Lx)) err = 1;
+  } else {  // polar cell: co-latitude tangent plane (FW:6359-6404), cold
+    const double pi_180 = p.pi / 180.;
+    const double xx = (90. - y) * cos(x * pi_180), yy = (90. - y) * sin(x * pi_180);
+    const double x1 = (90. - q.lat00) * cos(q.lon00 * pi_180), y1 = (90. - q.lat00) * sin(q.lon00 * pi_180);
+    const double x2 = (90. - q.lat10) * cos(q.lon10 * pi_180), y2 = (90. - q.lat10) * sin(q.lon10 * pi_180);
+    const double x3 = (90. - q.lat11) * cos(q.lon11 * pi_180), y3 = (90. - q.lat11) * sin(q.lon11 * pi_180);
+    const double x4 = (90. - q.lat01) * cos(q.lon01 * pi_180), y4 = (90. - q.lat01) * sin(q.lon01 * pi_180);
+    if (!calc_xiyj(x1, x2, x3, x4, y1, y2, y3, y4, xx, yy, xi, yj, g.Lx)) err = 1;
+    if (is_point_in_cell(g, q, x, y)) {
+      if (!((xi >= 0. && xi < 1.) && (yj >= 0. && yj < 1.))) {
+        double fac = 2.1 * dmax(fabs(xi - 0.5), fabs(yj - 0.5)); fac = dmax(1., fac);
+        xi = 0.5 + (xi - 0.5) / fac;
+        yj = 0.5 + (yj - 0.5) / fac;
+      }
+    } else if (fabs(xi - 0.5) < 0.5 && fabs(yj - 0.5) < 0.5) err = 1;
+  }
+  return is_point_in_cell(g, q, x, y);
+}
+
+// FW:7071-7088 on the corner coordinates (used when a berg bounces, IB:7990-7991, 8050-8051)
+__device__ __forceinline__ void bilin_lonlat(const DevGrid &g, const kid_params &p, int i, int j, double xi, double yj,
+                                             double &lon, double &lat) {
+  const Corners q = load_corners(g, i, j);
+  if (p.old_bug_bilin) {
+    lon = (q.lon11 * (1. - xi) + q.lon01 * xi) * (1. - yj) + (q.lon10 * (1. - xi) + q.lon00 * xi) * yj;
+    lat = (q.lat11 * (1. - xi) + q.lat01 * xi) * (1. - yj) + (q.lat10 * (1. - xi) + q.lat00 * xi) * yj;
+  } else {
+    lon = (q.lon11 * xi + q.lon01 * (1. - xi)) * yj + (q.lon10 * xi + q.lon00 * (1. - xi)) * (1. - yj);
+    lat = (q.lat11 * xi + q.lat01 * (1. - xi)) * yj + (q.lat10 * xi + q.lat00 * (1. - xi)) * (1. - yj);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IB:4718-4900 interp_flds (non-MTS; tidal_drift = 0)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void interp_flds(const DevGrid &g, const kid_params &p, int i, int j, double xi, double yj, Env &e) {
+  const int c = g.idx(i, j);
+  const VelRec v11 = g.vel[c], v01 = g.vel[c - 1], v10 = g.vel[c - g.ni], v00 = g.vel[c - g.ni - 1];
+  double wx1, wx0, wy1, wy0;  // weights of columns i / i-1 and rows j / j-1 (FW:7081-7087)
+  if (p.old_bug_bilin) { wx1 = 1. - xi; wx0 = xi; wy1 = 1. - yj; wy0 = yj; }
+  else { wx1 = xi; wx0 = 1. - xi; wy1 = yj; wy0 = 1. - yj; }
+#define KID_BIL(f) ((v11.f * wx1 + v01.f * wx0) * wy1 + (v10.f * wx1 + v00.f * wx0) * wy0)
+  const double cos_rot = KID_BIL(cosr), sin_rot = KID_BIL(sinr);
+  double uo = KID_BIL(uo), vo = KID_BIL(vo), ui = KID_BIL(ui), vi = KID_BIL(vi), ua = KID_BIL(ua), va = KID_BIL(va);
+#undef KID_BIL
+  const TrcRec t0 = g.trc[c];
+  if (p.coastal_drift > 0.) {  // IB:4769-4776
+    const double mE = g.trc[c + 1].msk, mW = g.trc[c - 1].msk, mN = g.trc[c + g.ni].msk, mS = g.trc[c - g.ni].msk;
+    uo = uo + p.coastal_drift * (mE - mW) * t0.msk;
+    ui = ui + p.coastal_drift * (mE - mW) * t0.msk;
+    vo = vo + p.coastal_drift * (mN - mS) * t0.msk;
+    vi = vi + p.coastal_drift * (mN - mS) * t0.msk;
+  }
+  // sea-surface slope from the hoisted per-cell stencils (IB:4830-4860)
+  double hxp, hxm;
+  const double ddx_00 = t0.ddx, ddx_m0 = g.trc[c - 1].ddx;
+  if (yj >= 0.5) {
+    hxp = (yj - 0.5) * g.trc[c + g.ni].ddx + (1.5 - yj) * ddx_00;
+    hxm = (yj - 0.5) * g.trc[c + g.ni - 1].ddx + (1.5 - yj) * ddx_m0;
+  } else {
+    hxp = (yj + 0.5) * ddx_00 + (0.5 - yj) * g.trc[c - g.ni].ddx;
+    hxm = (yj + 0.5) * ddx_m0 + (0.5 - yj) * g.trc[c - g.ni - 1].ddx;
+  }
+  double ssh_x = xi * hxp + (1. - xi) * hxm;
+  const double ddy_00 = t0.ddy, ddy_0m = g.trc[c - g.ni].ddy;
+  if (xi >= 0.5) {
+    hxp = (xi - 0.5) * g.trc[c + 1].ddy + (1.5 - xi) * ddy_00;
+    hxm = (xi - 0.5) * g.trc[c + 1 - g.ni].ddy + (1.5 - xi) * ddy_0m;
+  } else {
+    hxp = (xi + 0.5) * ddy_00 + (0.5 - xi) * g.trc[c - 1].ddy;
+    hxm = (xi + 0.5) * ddy_0m + (0.5 - xi) * g.trc[c - 1 - g.ni].ddy;
+  }
+  double ssh_y = yj * hxp + (1. - yj) * hxm;
+  // rotate to lat-lon (IB:4953-4967)
+  double t;
+  t = uo; uo = cos_rot * t + sin_rot * vo; vo = cos_rot * vo - sin_rot * t;
+  t = ui; ui = cos_rot * t + sin_rot * vi; vi = cos_rot * vi - sin_rot * t;
+  t = ua; ua = cos_rot * t + sin_rot * va; va = cos_rot * va - sin_rot * t;
+  t = ssh_x; ssh_x = cos_rot * t + sin_rot * ssh_y; ssh_y = cos_rot * ssh_y - sin_rot * t;
+  if (ssh_x != ssh_x) ssh_x = 0.;
+  if (ssh_y != ssh_y) ssh_y = 0.;
+  e.uo = uo; e.vo = vo; e.ui = ui; e.vi = vi; e.ua = ua; e.va = va; e.ssh_x = ssh_x; e.ssh_y = ssh_y;
+  e.sst = t0.sst; e.sss = t0.sss; e.cn = t0.cn; e.hi = t0.hi; e.od = t0.od;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IB:1950-2442 accel, non-interactive bergs
+// ---------------------------------------------------------------------------------------------------------
+struct BergGeom { double M, T, W, L; int n_bonds; };
+
+template <bool RK>
+__device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &e,
+                                      int i, int j, double sin_lat, double uvel, double vvel, double uvel0, double vvel0,
+                                      double dt, double &ax, double &ay, double &axn, double &ayn, double &bxn, double &byn,
+                                      unsigned &tickets) {
+  // RK: alpha=0, C_N=0, predictive-corrective per namelist; Verlet: alpha=C_N=1, predictive-corrective forced (IB:2002-2013)
+  const bool new_pc = RK ? (p.use_new_predictive_corrective != 0) : true;
+  const double u_star = uvel0 + (axn * (dt / 2.)), v_star = vvel0 + (ayn * (dt / 2.));
+  const double uo = e.uo, vo = e.vo, ui = e.ui, vi = e.vi, ua = e.ua, va = e.va;
+  const double f_cori = (2. * p.omega) * sin_lat;  // IB:2043-2047, the caller picks lat or lat_ref
+  const double M = bg.M, T = bg.T, W = bg.W, L = bg.L;
+  const double D = (p.rho_bergs / RHO_SEAWATER) * T, F = T - D;
+  const double hi = dmin(e.hi, D), D_hi = dmax(0., D - hi);
+  double c_gnd = 0.;
+  {  // grounding drag IB:2068-2082
+    double groundfrac;
+    if (p.h_to_init_grounding > 0.0) {
+      groundfrac = 1.0 - (e.od - D) / p.h_to_init_grounding;
+      groundfrac = dmax(groundfrac, 0.0); groundfrac = dmin(groundfrac, 1.0);
+    } else groundfrac = (D > e.od) ? 1.0 : 0.0;
+    if (groundfrac > 0.0) c_gnd = (p.cdrag_grounding * W * L * groundfrac) / M;
+  }
+  // wave radiation IB:2085-2102
+  double uwave = ua - uo, vwave = va - vo;
+  double wmod = uwave * uwave + vwave * vwave;
+  const double ampl = 0.5 * 0.02025 * wmod, Lwavelength = 0.32 * wmod;
+  const double Lcutoff = 0.125 * Lwavelength, Ltop = 0.25 * Lwavelength;
+  const double Cr = 0.06 * dmin(dmax(0., (L - Lcutoff) / ((Ltop - Lcutoff) + 1.e-30)), 1.);
+  double wave_rad = 0.5 * RHO_SEAWATER / M * Cr * GRAVITY * ampl * dmin(ampl, F) * (2. * W * L) / (W + L);
+  wmod = sqrt(ua * ua + va * va);
+  if (wmod != 0.) { uwave = ua / wmod; vwave = va / wmod; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
+  double dragfrac = 1.0;
+  if (p.iceberg_bonds_on && p.internal_bergs_for_drag) {
+    const double N_max = p.hexagonal_icebergs ? 6.0 : 4.0;
+    dragfrac = ((N_max - (double)bg.n_bonds) / N_max);
+  }
+  const double c_ocn = RHO_SEAWATER / M * p.ocean_drag_scale * (0.5 * CD_WV * dragfrac * W * (D_hi) + CD_WH * W * L);
+  const double c_atm = RHO_AIR / M * (0.5 * CD_AV * dragfrac * W * F + CD_AH * W * L);
+  double c_ice = (fabs(hi) == 0.) ? 0. : RHO_ICE / M * (0.5 * CD_IV * dragfrac * W * hi);
+  if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.;
+  const double ex = -GRAVITY * e.ssh_x + wave_rad * uwave, ey = -GRAVITY * e.ssh_y + wave_rad * vwave;  // IB:2142-2149
+  double axn_l, ayn_l, bxn_l, byn_l;
+  if (RK) { axn_l = 0.; ayn_l = 0.; bxn_l = ex + f_cori * vvel; byn_l = ey - f_cori * uvel; }          // IB:2172-2173
+  else    { axn_l = ex + f_cori * v_star; ayn_l = ey - f_cori * u_star; bxn_l = 0.; byn_l = 0.; }      // IB:2165-2166
+  double uveln = new_pc ? uvel0 : uvel, vveln = new_pc ? vvel0 : vvel;
+  // the |V0 - V_x| halves of the predictive-corrective drag do not change between the two passes
+  double s0o = 0., s0a = 0., s0i = 0.;
+  if (new_pc) {
+    s0o = sqrt((uvel0 - uo) * (uvel0 - uo) + (vvel0 - vo) * (vvel0 - vo));
+    s0a = sqrt((uvel0 - ua) * (uvel0 - ua) + (vvel0 - va) * (vvel0 - va));
+    s0i = sqrt((uvel0 - ui) * (uvel0 - ui) + (vvel0 - vi) * (vvel0 - vi));
+  }
+  const double A12_0 = RK ? -0. * dt * f_cori : (-1. * dt * f_cori) / 2.;  // IB:2244-2251 (alpha, C_N)
+  const double A21_0 = RK ? 0. * dt * f_cori : (1. * dt * f_cori) / 2.;
+  ax = 0.; ay = 0.;
+#pragma unroll
+  for (int itloop = 1; itloop <= 2; ++itloop) {  // IB:2183-2277
+    double drag_ocn, drag_atm, drag_ice;
+    if (new_pc) {
+      drag_ocn = c_ocn * 0.5 * (sqrt((uveln - uo) * (uveln - uo) + (vveln - vo) * (vveln - vo)) + s0o);
+      drag_atm = c_atm * 0.5 * (sqrt((uveln - ua) * (uveln - ua) + (vveln - va) * (vveln - va)) + s0a);
+      drag_ice = c_ice * 0.5 * (sqrt((uveln - ui) * (uveln - ui) + (vveln - vi) * (vveln - vi)) + s0i);
+    } else {
+      const double us = 0.5 * (uveln + uvel), vs = 0.5 * (vveln + vvel);
+      drag_ocn = c_ocn * sqrt((us - uo) * (us - uo) + (vs - vo) * (vs - vo));
+      drag_atm = c_atm * sqrt((us - ua) * (us - ua) + (vs - va) * (vs - va));
+      drag_ice = c_ice * sqrt((us - ui) * (us - ui) + (vs - vi) * (vs - vi));
+    }
+    const double drag_gnd = c_gnd;
+    double RHS_x = (axn_l / 2) + bxn_l, RHS_y = (ayn_l / 2) + byn_l;
+    RHS_x = RHS_x - drag_ocn * (u_star - uo) - drag_atm * (u_star - ua) - drag_ice * (u_star - ui) - drag_gnd * u_star;  // beta=1
+    RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va) - drag_ice * (v_star - vi) - drag_gnd * v_star;
+    const double lambda = drag_ocn + drag_atm + drag_ice + drag_gnd;
+    const double A11 = 1. + 1.0 * dt * lambda, A22 = 1. + 1.0 * dt * lambda;
+    const double detA = 1. / ((A11 * A22) - (A12_0 * A21_0));
+    ax = detA * (A22 * RHS_x - A12_0 * RHS_y);
+    ay = detA * (A11 * RHS_y - A21_0 * RHS_x);
+    uveln = u_star + dt * ax;
+    vveln = v_star + dt * ay;
+  }
+  if (RK) { axn = 0.; ayn = 0.; }                                               // IB:2286
+  else    { axn = ex + f_cori * vveln; ayn = ey - f_cori * uveln; }              // IB:2288-2297
+  bxn = ax - (axn / 2); byn = ay - (ayn / 2);
+  if (p.speed_limit > 0. || p.speed_limit == -1.) {  // IB:2304-2323: only the ticket counter survives
+    const double speed = sqrt(uveln * uveln + vveln * vveln);
+    if (speed > 0.) {
+      const int c = g.idx(i, j);
+      const double loc_dx = dmin(0.5 * (g.dx[c] + g.dx[c - g.ni]), 0.5 * (g.dy[c] + g.dy[c - 1]));
+      const double new_speed = loc_dx / dt * p.speed_limit;
+      if (new_speed < speed && p.speed_limit > 0.) tickets += 1u;
+    }
+  }
+  if (p.override_iceberg_velocities) { ax = 0.; ay = 0.; axn = 0.; ayn = 0.; bxn = 0.; byn = 0.; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IB:7819-8063 adjust_index_and_ground (debug=.false.)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, double &lon, double &lat,
+                                                        int &i, int &j, double &xi, double &yj, int &err) {
+  constexpr double posn_eps = 0.05;
+  bool lret = pos_within_cell(g, p, lon, lat, i, j, xi, yj, err);
+  if (lret) return;  // the common case: still in its cell
+  // cold path: hop cells / bounce off land.  (The second pos_within_cell(i0,j0) of IB:7940 repeats the call above.)
+  const int i0 = i, j0 = j;
+  bool bounced = false;
+  for (int icount = 0; !lret && icount < 4; ++icount) {
+    if (xi < 0.) {
+      if (i > g.isd) { if (g.geo[g.idx(i - 1, j)].msk > 0.) { if (i > g.isd + 1) i = i - 1; } else bounced = true; }
+    } else if (xi >= 1.) {
+      if (i < g.ied) { if (g.geo[g.idx(i + 1, j)].msk > 0.) { if (i < g.ied) i = i + 1; } else bounced = true; }
+    }
+    if (yj < 0.) {
+      if (j > g.jsd) { if (g.geo[g.idx(i, j - 1)].msk > 0.) { if (j > g.jsd + 1) j = j - 1; } else bounced = true; }
+    } else if (yj >= 1.) {
+      if (j < g.jed) { if (g.geo[g.idx(i, j + 1)].msk > 0.) { if (j < g.jed) j = j + 1; } else bounced = true; }
+    }
+    if (bounced) {
+      if (xi >= 1.) xi = 1. - posn_eps;
+      if (xi < 0.) xi = posn_eps;
+      if (yj >= 1.) yj = 1. - posn_eps;
+      if (yj < 0.) yj = posn_eps;
+      bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
+    }
+    lret = pos_within_cell(g, p, lon, lat, i, j, xi, yj, err);
+  }
+  if (!bounced && lret && g.geo[g.idx(i, j)].msk > 0.) return;
+  if (!bounced && !lret) {
+    if (abs(i - i0) + abs(j - j0) == 0 && p.use_roundoff_fix) {  // IB:8024-8034
+      xi = (xi - 0.5) * (1. - posn_eps) + 0.5;
+      yj = (yj - 0.5) * (1. - posn_eps) + 0.5;
+    }
+  }
+  if (xi >= 1.) xi = 1. - posn_eps;   // asymmetric clamps IB:8045-8049
+  if (xi < 0.) xi = posn_eps;
+  if (yj > 1.) yj = 1. - posn_eps;
+  if (yj <= 0.) yj = posn_eps;
+  bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
+  (void)pos_within_cell(g, p, lon, lat, i, j, xi, yj, err);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// polar tangent plane, IB:7767-7816, 8066-8099 (cold: lat > 89)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __noinline__ void rotpos_to_tang(const kid_params &p, double lon, double lat, double &x, double &y) {
+  const double pi_180 = p.pi / 180.;
+  const double r = p.Rearth * ((90. - lat) * pi_180);
+  x = r * cos(lon * pi_180); y = r * sin(lon * pi_180);
+}
+__device__ __noinline__ void rotpos_from_tang(const kid_params &p, double x, double y, double &lon, double &lat) {
+  const double r180_pi = 180. / p.pi;
+  const double r = sqrt(x * x + y * y);
+  lat = 90. - (r180_pi * r / p.Rearth);
+  lon = r180_pi * acos(x / r) * sign1(y);
+}
+__device__ __noinline__ void rotvec_to_tang(const kid_params &p, double lon, double uvel, double vvel, double &xdot, double &ydot) {
+  const double pi_180 = p.pi / 180.;
+  const double clon = cos(lon * pi_180), slon = sin(lon * pi_180);
+  xdot = -slon * uvel - clon * vvel; ydot = clon * uvel - slon * vvel;
+}
+__device__ __noinline__ void rotvec_from_tang(const kid_params &p, double lon, double xdot, double ydot, double &uvel, double &vvel) {
+  const double pi_180 = p.pi / 180.;
+  const double clon = cos(lon * pi_180), slon = sin(lon * pi_180);
+  uvel = -slon * xdot + clon * ydot; vvel = -clon * xdot - slon * ydot;
+}
+
+// sin(lat) for Coriolis (IB:2043-2047) and the metric dlon/dx (IB:462-477) share one argument reduction
+struct LatTerms { double sin_f, dxdl; };
+__device__ __forceinline__ LatTerms lat_terms(const DevGrid &g, const kid_params &p, double lat, double sin_ref) {
+  LatTerms t;
+  if (g.latlon) {
+    double s, c;
+    sincos(lat * (p.pi / 180.), &s, &c);
+    t.dxdl = (180. / p.pi) / (p.Rearth * c);
+    t.sin_f = p.use_f_plane ? sin_ref : s;
+  } else { t.dxdl = 1.; t.sin_f = sin_ref; }
+  return t;
+}
+
+// per-berg dynamic state carried through one step
+struct BergDyn {
+  double lon, lat, uvel, vvel, axn, ayn, bxn, byn, xi, yj, uvel_prev, vvel_prev;
+  int ine, jne;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// IB:7331-7679 Runge_Kutta_stepping.  env is only read when .not.old_interp_flds_order.
+// ---------------------------------------------------------------------------------------------------------
+template <bool OLD_ORDER>
+__device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
+                                         BergDyn &d, unsigned &tickets, int &err) {
+  const double dt = p.dt, dt_2 = 0.5 * dt, dt_6 = dt / 6.;
+  const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
+  const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
+  const int i1 = d.ine, j1 = d.jne;
+  const double xi1 = d.xi, yj1 = d.yj, lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
+  const bool on_tang = (lat1 > 89.) && g.latlon;
+  Env e = stored;
+  double bxn = 0., byn = 0.;
+  // stage 1
+  double x1 = 0, y1 = 0, xdot1 = 0, ydot1 = 0;
+  if (on_tang) { rotpos_to_tang(p, lon1, lat1, x1, y1); rotvec_to_tang(p, lon1, uvel1, vvel1, xdot1, ydot1); }
+  LatTerms lt = lat_terms(g, p, lat1, sin_ref);
+  const double u1 = uvel1 * lt.dxdl, v1 = vvel1 * dydl;
+  double ax1, ay1, axn1 = d.axn, ayn1 = d.ayn;
+  if (OLD_ORDER) interp_flds(g, p, i1, j1, xi1, yj1, e);
+  accel<true>(g, p, bg, e, i1, j1, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt_2, ax1, ay1, axn1, ayn1, bxn, byn, tickets);
+  double xddot1 = 0, yddot1 = 0, xddot1n = 0, yddot1n = 0;
+  if (on_tang) { rotvec_to_tang(p, lon1, ax1, ay1, xddot1, yddot1); rotvec_to_tang(p, lon1, axn1, ayn1, xddot1n, yddot1n); }
+  // stage 2
+  double lon2, lat2, uvel2, vvel2, xdot2 = 0, ydot2 = 0;
+  if (on_tang) {
+    const double x2 = x1 + dt_2 * xdot1, y2 = y1 + dt_2 * ydot1;
+    xdot2 = xdot1 + dt_2 * xddot1; ydot2 = ydot1 + dt_2 * yddot1;
+    rotpos_from_tang(p, x2, y2, lon2, lat2); rotvec_from_tang(p, lon2, xdot2, ydot2, uvel2, vvel2);
+  } else { lon2 = lon1 + dt_2 * u1; lat2 = lat1 + dt_2 * v1; uvel2 = uvel1 + dt_2 * ax1; vvel2 = vvel1 + dt_2 * ay1; }
+  int i = i1, j = j1; double xi = xi1, yj = yj1;
+  adjust_index_and_ground(g, p, lon2, lat2, i, j, xi, yj, err);
+  lt = lat_terms(g, p, lat2, sin_ref);
+  const double u2 = uvel2 * lt.dxdl, v2 = vvel2 * dydl;
+  double ax2, ay2, axn2 = d.axn, ayn2 = d.ayn;
+  if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
+  accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel2, vvel2, uvel1, vvel1, dt_2, ax2, ay2, axn2, ayn2, bxn, byn, tickets);
+  double xddot2 = 0, yddot2 = 0, xddot2n = 0, yddot2n = 0;
+  if (on_tang) { rotvec_to_tang(p, lon2, ax2, ay2, xddot2, yddot2); rotvec_to_tang(p, lon2, axn2, ayn2, xddot2n, yddot2n); }
+  // stage 3
+  double lon3, lat3, uvel3, vvel3, xdot3 = 0, ydot3 = 0;
+  if (on_tang) {
+    const double x3 = x1 + dt_2 * xdot2, y3 = y1 + dt_2 * ydot2;
+    xdot3 = xdot1 + dt_2 * xddot2; ydot3 = ydot1 + dt_2 * yddot2;
+    rotpos_from_tang(p, x3, y3, lon3, lat3); rotvec_from_tang(p, lon3, xdot3, ydot3, uvel3, vvel3);
+  } else { lon3 = lon1 + dt_2 * u2; lat3 = lat1 + dt_2 * v2; uvel3 = uvel1 + dt_2 * ax2; vvel3 = vvel1 + dt_2 * ay2; }
+  i = i1; j = j1; xi = xi1; yj = yj1;
+  adjust_index_and_ground(g, p, lon3, lat3, i, j, xi, yj, err);
+  lt = lat_terms(g, p, lat3, sin_ref);
+  const double u3 = uvel3 * lt.dxdl, v3 = vvel3 * dydl;
+  double ax3, ay3, axn3 = d.axn, ayn3 = d.ayn;
+  if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
+  accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel3, vvel3, uvel1, vvel1, dt, ax3, ay3, axn3, ayn3, bxn, byn, tickets);
+  double xddot3 = 0, yddot3 = 0, xddot3n = 0, yddot3n = 0;
+  if (on_tang) { rotvec_to_tang(p, lon3, ax3, ay3, xddot3, yddot3); rotvec_to_tang(p, lon3, axn3, ayn3, xddot3n, yddot3n); }
+  // stage 4
+  double lon4, lat4, uvel4, vvel4, xdot4 = 0, ydot4 = 0;
+  if (on_tang) {
+    const double x4 = x1 + dt * xdot3, y4 = y1 + dt * ydot3;
+    xdot4 = xdot1 + dt * xddot3; ydot4 = ydot1 + dt * yddot3;
+    rotpos_from_tang(p, x4, y4, lon4, lat4); rotvec_from_tang(p, lon4, xdot4, ydot4, uvel4, vvel4);
+  } else { lon4 = lon1 + dt * u3; lat4 = lat1 + dt * v3; uvel4 = uvel1 + dt * ax3; vvel4 = vvel1 + dt * ay3; }
+  i = i1; j = j1; xi = xi1; yj = yj1;
+  adjust_index_and_ground(g, p, lon4, lat4, i, j, xi, yj, err);
+  lt = lat_terms(g, p, lat4, sin_ref);
+  const double u4 = uvel4 * lt.dxdl, v4 = vvel4 * dydl;
+  double ax4, ay4, axn4 = d.axn, ayn4 = d.ayn;
+  if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
+  accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel4, vvel4, uvel1, vvel1, dt, ax4, ay4, axn4, ayn4, bxn, byn, tickets);
+  // combine IB:7597-7616
+  double lonn, latn, uveln, vveln, axn, ayn;
+  if (on_tang) {
+    double xddot4, yddot4, xddot4n, yddot4n;
+    rotvec_to_tang(p, lon4, ax4, ay4, xddot4, yddot4); rotvec_to_tang(p, lon4, axn4, ayn4, xddot4n, yddot4n);
+    const double xn = x1 + dt_6 * ((xdot1 + xdot4) + 2. * (xdot2 + xdot3));
+    const double yn = y1 + dt_6 * ((ydot1 + ydot4) + 2. * (ydot2 + ydot3));
+    const double xdotn = xdot1 + dt_6 * ((xddot1 + xddot4) + 2. * (xddot2 + xddot3));
+    const double ydotn = ydot1 + dt_6 * ((yddot1 + yddot4) + 2. * (yddot2 + yddot3));
+    const double xddotn = ((xddot1n + xddot4n) + 2. * (xddot2n + xddot3n)) / 6.;
+    const double yddotn = ((yddot1n + yddot4n) + 2. * (yddot2n + yddot3n)) / 6.;
+    rotpos_from_tang(p, xn, yn, lonn, latn);
+    rotvec_from_tang(p, lonn, xdotn, ydotn, uveln, vveln);
+    rotvec_from_tang(p, lonn, xddotn, yddotn, axn, ayn);  // bxn,byn stay as the 4th accel left them
+  } else {
+    lonn = lon1 + dt_6 * ((u1 + u4) + 2. * (u2 + u3));
+    latn = lat1 + dt_6 * ((v1 + v4) + 2. * (v2 + v3));
+    uveln = uvel1 + dt_6 * ((ax1 + ax4) + 2. * (ax2 + ax3));
+    vveln = vvel1 + dt_6 * ((ay1 + ay4) + 2. * (ay2 + ay3));
+    axn = ((axn1 + axn4) + 2. * (axn2 + axn3)) / 6.;
+    ayn = ((ayn1 + ayn4) + 2. * (ayn2 + ayn3)) / 6.;
+    bxn = (((ax1 + ax4) + 2. * (ax2 + ax3)) / 6) - (axn / 2);
+    byn = (((ay1 + ay4) + 2. * (ay2 + ay3)) / 6) - (ayn / 2);
+  }
+  i = i1; j = j1; xi = xi1; yj = yj1;
+  adjust_index_and_ground(g, p, lonn, latn, i, j, xi, yj, err);
+  if (p.override_iceberg_velocities) { uveln = p.u_override; vveln = p.v_override; }  // IB:7151-7154
+  d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
+  d.xi = xi; d.yj = yj; d.ine = i; d.jne = j;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IB:7203-7328 verlet_stepping + IB:7684-7764 update_verlet_position (non-interactive)
+// ---------------------------------------------------------------------------------------------------------
+template <bool OLD_ORDER>
+__device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
+                                            BergDyn &d, unsigned &tickets, int &err) {
+  const double dt = p.dt, dt_2 = 0.5 * dt;
+  const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
+  const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
+  const double lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
+  double axn = d.axn, ayn = d.ayn, bxn = d.bxn, byn = d.byn;
+  d.uvel_prev = d.uvel - dt_2 * d.bxn; d.vvel_prev = d.vvel - dt_2 * d.byn;       // IB:7256
+  const double uvel3 = uvel1 + (dt_2 * axn), vvel3 = vvel1 + (dt_2 * ayn);         // IB:7259-7260
+  const LatTerms lt = lat_terms(g, p, lat1, sin_ref);
+  Env e = stored;
+  if (OLD_ORDER) interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e);
+  double ax1, ay1, uveln, vveln;
+  accel<false>(g, p, bg, e, d.ine, d.jne, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt, ax1, ay1, axn, ayn, bxn, byn, tickets);
+  const bool on_tang = (lat1 > 89.) && g.latlon;
+  if (on_tang) {
+    double xdot3, ydot3, xddot1, yddot1;
+    rotvec_to_tang(p, lon1, uvel3, vvel3, xdot3, ydot3);
+    rotvec_to_tang(p, lon1, ax1, ay1, xddot1, yddot1);
+    rotvec_from_tang(p, lon1, xdot3 + (dt * xddot1), ydot3 + (dt * yddot1), uveln, vveln);
+  } else { uveln = uvel3 + (dt * ax1); vveln = vvel3 + (dt * ay1); }
+  if (p.override_iceberg_velocities) { uveln = p.u_override; vveln = p.v_override; }
+  // update_verlet_position reads berg%uvel AFTER the write-back (IB:7161 then 7720): u_new + dt/2 (axn+bxn)
+  const double uvel2 = uveln + (dt_2 * axn) + (dt_2 * bxn), vvel2 = vveln + (dt_2 * ayn) + (dt_2 * byn);
+  double lonn, latn;
+  if (on_tang) {
+    double x1, y1, xdot2, ydot2;
+    rotpos_to_tang(p, lon1, lat1, x1, y1);
+    rotvec_to_tang(p, lon1, uvel2, vvel2, xdot2, ydot2);
+    rotpos_from_tang(p, x1 + (dt * xdot2), y1 + (dt * ydot2), lonn, latn);
+  } else {
+    const double u2 = uvel2 * lt.dxdl, v2 = vvel2 * dydl;
+    lonn = lon1 + (dt * u2); latn = lat1 + (dt * v2);
+  }
+  adjust_index_and_ground(g, p, lonn, latn, d.ine, d.jne, d.xi, d.yj, err);
+  d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IB:3307-3364 rolling, IB:3370-3387 fl_bits_dimensions
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swapd(double &x, double &y) { const double t = x; x = y; y = t; }
+__device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double &Wn, double &Ln) {
+  const double q = p.rho_bergs / RHO_SEAWATER;
+  const double Dn = q * Tn;
+  if (Dn > 0.) {
+    if (!p.use_updated_rolling_scheme && p.tip_parameter < 999.) {          // scheme 3 (default)
+      if (dmax(Wn, Ln) < sqrt(0.92 * (Dn * Dn) + 58.32 * Dn)) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
+    } else {
+      if (Wn > Ln) swapd(Ln, Wn);
+      if (!p.use_updated_rolling_scheme && p.tip_parameter >= 999.) {       // scheme 2
+        if (Wn < sqrt((6.0 * q * (1 - q) * (Tn * Tn)) - (12 * 6.0 * q * Tn))) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
+      }
+      if (p.use_updated_rolling_scheme) {                                   // scheme 1
+        const double tip = (p.tip_parameter > 0.) ? p.tip_parameter : sqrt(6 * q * (1 - q));
+        if ((tip * Tn) > Wn) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void fl_bits_dimensions(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
+  const double l_c = p.pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = 1. / (12. * (1. - pow(0.3, 2.)));
+  const double l_w = pow(lw_c * p.fl_youngs * B_c * pow(thickness, 3.), 0.25);
+  const double l_b = l_c * l_w;
+  L_fl = 3. * l_b; W_fl = l_b; T_fl = thickness;
+  rolling(p, T_fl, W_fl, L_fl);
+}
+
+// IB:3492-3785 find_basal_melt (cold: only with melt_icebergs_as_ice_shelf / use_mixed_melting)
+__device__ __noinline__ double find_basal_melt(const DevGrid &g, const kid_params &p, double dvo, double lat, double salt,
+                                               double temp, bool three_eq, double thickness) {
+  const double VK = 0.40, ZETA_N = 0.052, RC = 0.20, c2_3 = 2.0 / 3.0;
+  const double dR0_dT = -0.038357, dR0_dS = 0.805876, RHO_T0_S0 = 999.910681, Salin_Ice = 0.0;
+  const double kd_molec_salt = 8.02e-10, kd_molec_temp = 1.41e-7, kv_molec = 1.95e-6;
+  const double Cp_ml = 3974.0, LF = 3.335e5, p_atm = 101325;
+  const double dTFr_dp = -7.53E-08, dTFr_dS = -0.0573, TFr_S0_P0 = 0.0832;
+  const double density_ice = p.rho_bergs, Rho0 = RHO_SEAWATER, Hml = 10.;
+  const double p_int = p_atm + (GRAVITY * thickness * density_ice);
+  const double Rhoml = RHO_T0_S0 + dR0_dT * temp + dR0_dS * salt;
+  const double I_ZETA_N = 1.0 / ZETA_N, I_LF = 1.0 / LF, I_VK = 1.0 / VK, RhoCp = Rho0 * Cp_ml;
+  const double Gam_mol_t = 12.5 * pow(kv_molec / kd_molec_temp, c2_3) - 6, Gam_mol_s = 12.5 * pow(kv_molec / kd_molec_salt, c2_3) - 6;
+  const double ustar_h = dmax(p.ustar_icebergs_bg, sqrt(p.cdrag_icebergs * (dvo * dvo + p.utide_icebergs * p.utide_icebergs)));
+  const double f_cori = (2. * p.omega) * sin((p.pi / 180.) * ((g.latlon && !p.use_f_plane) ? lat : p.lat_ref));
+  const double absf = fabs(f_cori);
+  const double hBL_neut = ((absf * Hml <= VK * ustar_h) || (absf == 0.)) ? Hml : (VK * ustar_h) / absf;
+  const double hBL_neut_h_molec = ZETA_N * ((hBL_neut * ustar_h) / (5.0 * kv_molec));
+  const double ln_neut = (hBL_neut_h_molec > 1.0) ? log(hBL_neut_h_molec) : 0.0;
+  double lprec = 0., I_Gam_T = 0., I_Gam_S = 0., wT_flux = 0.;
+  bool out_of_bounds = false;
+  if (three_eq) {
+    double Sbdry = salt, Sb_max = 0, Sb_min = 0;
+    bool Sb_max_set = false, Sb_min_set = false;
+    const double dB_dS = (GRAVITY / Rhoml) * dR0_dS, dB_dT = (GRAVITY / Rhoml) * dR0_dT;
+    for (int it1 = 1; it1 <= 20; ++it1) {
+      const double tfreeze = (TFr_S0_P0 + dTFr_dS * Sbdry) + dTFr_dp * p_int;
+      const double dT_ustar = (temp - tfreeze) * ustar_h, dS_ustar = (salt - Sbdry) * ustar_h;
+      if (p.const_gamma) { I_Gam_T = p.Gamma_T_3EQ; I_Gam_S = p.Gamma_T_3EQ / 35.; }
+      else {
+        const double Gam_turb = I_VK * (ln_neut + (0.5 * I_ZETA_N - 1.0));
+        I_Gam_T = 1.0 / (Gam_mol_t + Gam_turb); I_Gam_S = 1.0 / (Gam_mol_s + Gam_turb);
+      }
+      wT_flux = dT_ustar * I_Gam_T;
+      const double wB_flux = dB_dS * (dS_ustar * I_Gam_S) + dB_dT * wT_flux;
+      if (wB_flux > 0.0) {  // the Newton iterate is never fed back (IB:3661-3698): wB_flux is fixed
+        const double n_star_term = (ZETA_N / RC) * (hBL_neut * VK) / (ustar_h * ustar_h * ustar_h);
+        const double I_n_star = sqrt(1.0 + n_star_term * wB_flux);
+        double Gam_turb;
+        if (hBL_neut_h_molec > I_n_star * I_n_star) Gam_turb = I_VK * ((ln_neut - 2.0 * log(I_n_star)) + (0.5 * I_ZETA_N * I_n_star - 1.0));
+        else Gam_turb = I_VK * (0.5 * I_ZETA_N * I_n_star - 1.0);
+        if (p.const_gamma) { I_Gam_T = p.Gamma_T_3EQ; I_Gam_S = p.Gamma_T_3EQ / 35.; }
+        else { I_Gam_T = 1.0 / (Gam_mol_t + Gam_turb); I_Gam_S = 1.0 / (Gam_mol_s + Gam_turb); }
+        wT_flux = dT_ustar * I_Gam_T;
+      }
+      const double t_flux = RhoCp * wT_flux;
+      lprec = I_LF * t_flux;
+      const double mass_exch = (ustar_h * I_Gam_S) * Rho0;
+      const double Sbdry_it = (salt * mass_exch + Salin_Ice * lprec) / (mass_exch + lprec);
+      const double dS_it = Sbdry_it - Sbdry;
+      if (fabs(dS_it) < 1e-4 * (0.5 * (salt + Sbdry + 1.e-10))) break;
+      if (dS_it < 0.0) {
+        if (Sb_max_set && (Sbdry > Sb_max)) { out_of_bounds = true; break; }
+        Sb_max = Sbdry; Sb_max_set = true;
+      } else {
+        if (Sb_min_set && (Sbdry < Sb_min)) { out_of_bounds = true; break; }
+        Sb_min = Sbdry; Sb_min_set = true;
+      }
+      Sbdry = Sbdry_it;  // IB:3755
+    }
+  }
+  if (!three_eq || out_of_bounds) {
+    const double tfreeze = (TFr_S0_P0 + dTFr_dS * salt) + dTFr_dp * p_int;
+    const double Gam_turb = I_VK * (ln_neut + (0.5 * I_ZETA_N - 1.0));
+    I_Gam_T = 1.0 / (Gam_mol_t + Gam_turb);
+    wT_flux = (ustar_h * I_Gam_T) * (temp - tfreeze);
+    lprec = I_LF * (RhoCp * wT_flux);
+  }
+  return lprec / density_ice;
+}
+
+}  // namespace kid

@@ -1,0 +1,774 @@
+// kid_hip.hip -- kernels and C ABI of libkid_hip.so (gfx950 / MI355X).  See include/kid.h.
+//
+// Data layout in HBM
+//   bergs   : structure of arrays, one contiguous fp64/int32 array of `capacity` elements per field of the
+//             reference's `type iceberg` (FW:290-359), in reference traversal order (cell-major).
+//   grid    : the 11 static + 11 forcing planes as the host passes them, plus three packed record arrays
+//             (VelRec/TrcRec/GeoRec, kid_device.hpp) rebuilt by a prepass kernel whenever the forcing changes.
+//   accum   : KID_NACC planes of ni*nj fp64 + KID_NSCALAR scalars in ONE block (one RCCL all-reduce per step),
+//             followed by KID_NOUT derived planes.
+// Kernels
+//   pack_static / pack_forcing : per cell, builds the records and hoists the SSH-slope stencils (IB:4903-4926).
+//   berg_kernel<RK,OLD,PH>     : one lane per berg; PH selects interp / evolve / thermodynamics / spreading, so
+//                                the reference's phase-by-phase call sites and the fused per-step launch share
+//                                one body.  HBM-streaming on the SoA, grid served from L2 / Infinity Cache.
+//   gather_kernel              : per cell, the 9-point gather of sum_up_spread_fields (IB:6126-6138) + ustar.
+#include <cstdio>
+#include <cstring>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "../../include/kid.h"
+#include "kid_device.hpp"
+#include "kid_thermo.hpp"
+
+using namespace kid;
+
+namespace {
+
+enum : unsigned { PH_INTERP = 1u, PH_EVOLVE = 2u, PH_THERMO = 4u, PH_SPREAD = 8u };
+
+struct BergPtrs {
+  double *f[KID_NB_F64];
+  int32_t *i[KID_NB_I32];
+  int64_t *id;
+};
+struct Flags { int has_static, has_fl, store_env, pad; };
+
+// -------------------------------------------------------------------------------------------------------
+// grid prepass kernels
+// -------------------------------------------------------------------------------------------------------
+struct GridPlanes { const double *st[KID_NGRID_STATIC]; const double *fo[KID_NFORCING]; };
+
+__global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec *geo, int ncell) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncell) return;
+  GeoRec r;
+  r.lon = gp.st[KID_G_LON][c]; r.lat = gp.st[KID_G_LAT][c]; r.area = gp.st[KID_G_AREA][c]; r.msk = gp.st[KID_G_MSK][c];
+  geo[c] = r;
+}
+
+__global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec *vel, TrcRec *trc, int ni, int nj) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ni * nj) return;
+  const int il = c % ni, jl = c / ni;
+  VelRec v;
+  v.cosr = gp.st[KID_G_COS][c]; v.sinr = gp.st[KID_G_SIN][c];
+  v.uo = gp.fo[KID_F_UO][c]; v.vo = gp.fo[KID_F_VO][c]; v.ui = gp.fo[KID_F_UI][c]; v.vi = gp.fo[KID_F_VI][c];
+  v.ua = gp.fo[KID_F_UA][c]; v.va = gp.fo[KID_F_VA][c];
+  vel[c] = v;
+  const double *dx = gp.st[KID_G_DX], *dy = gp.st[KID_G_DY], *msk = gp.st[KID_G_MSK], *ssh = gp.fo[KID_F_SSH];
+  TrcRec t;
+  t.sst = gp.fo[KID_F_SST][c]; t.sss = gp.fo[KID_F_SSS][c]; t.cn = gp.fo[KID_F_CN][c]; t.hi = gp.fo[KID_F_HI][c];
+  t.od = gp.st[KID_G_OCEAN_DEPTH][c] + ssh[c];  // IB:4897
+  t.msk = msk[c];
+  t.ddx = 0.; t.ddy = 0.;
+  if (il + 1 < ni && jl >= 1) {  // ddx_ssh(i,j) IB:4903-4913
+    const double dxp = 0.5 * (dx[c + 1] + dx[c + 1 - ni]);
+    const double dx0 = 0.5 * (dx[c] + dx[c - ni]);
+    t.ddx = 2. * (ssh[c + 1] - ssh[c]) / (dx0 + dxp) * msk[c + 1] * msk[c];
+  }
+  if (jl + 1 < nj && il >= 1) {  // ddy_ssh(i,j) IB:4916-4926
+    const double dyp = 0.5 * (dy[c + ni] + dy[c + ni - 1]);
+    const double dy0 = 0.5 * (dy[c] + dy[c - 1]);
+    t.ddy = 2. * (ssh[c + ni] - ssh[c]) / (dy0 + dyp) * msk[c + ni] * msk[c];
+  }
+  trc[c] = t;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// the per-berg kernel
+// -------------------------------------------------------------------------------------------------------
+template <bool RK, bool OLD_ORDER, unsigned PH>
+__global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_params p, const BergPtrs b, const long long n,
+                                                   double *__restrict__ acc, const size_t ncell, const Flags fl) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  const bool inrange = k < n;
+  const long long kk = inrange ? k : (n - 1);
+  const bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
+  if (__ballot(was_alive) == 0ull) return;  // wave-uniform
+  double *scal = acc + (size_t)KID_NACC * ncell;
+
+  BergDyn d;
+  d.ine = b.i[KID_BI_INE][kk]; d.jne = b.i[KID_BI_JNE][kk];
+  d.xi = b.f[KID_B_XI][kk]; d.yj = b.f[KID_B_YJ][kk];
+  d.lon = b.f[KID_B_LON][kk]; d.lat = b.f[KID_B_LAT][kk];
+  d.uvel = b.f[KID_B_UVEL][kk]; d.vvel = b.f[KID_B_VVEL][kk];
+  d.uvel_prev = 0.; d.vvel_prev = 0.;
+  BergThermo t;
+  t.alive = was_alive;
+  t.M = b.f[KID_B_MASS][kk]; t.T = b.f[KID_B_THICKNESS][kk]; t.W = b.f[KID_B_WIDTH][kk]; t.L = b.f[KID_B_LENGTH][kk];
+  t.n_bonds = p.iceberg_bonds_on ? b.i[KID_BI_N_BONDS][kk] : 0;
+  t.static_berg = fl.has_static ? b.f[KID_B_STATIC_BERG][kk] : 0.;
+  const bool halo = fl.has_static ? (b.f[KID_B_HALO_BERG][kk] >= 0.5) : false;
+  Env e = {};
+  unsigned tickets = 0u;
+  int err = 0;
+  bool env_dirty = false;
+
+  if ((PH & PH_INTERP) || (!OLD_ORDER && (PH & (PH_EVOLVE | PH_THERMO)))) {
+    if (PH & PH_INTERP) {  // IB:4673-4715
+      if (was_alive && !halo) { interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e); env_dirty = true; }
+    } else {  // stored environment (.not.old_interp_flds_order), IB:2039-2040
+      e.uo = b.f[KID_B_UO][kk]; e.vo = b.f[KID_B_VO][kk]; e.ui = b.f[KID_B_UI][kk]; e.vi = b.f[KID_B_VI][kk];
+      e.ua = b.f[KID_B_UA][kk]; e.va = b.f[KID_B_VA][kk]; e.ssh_x = b.f[KID_B_SSH_X][kk]; e.ssh_y = b.f[KID_B_SSH_Y][kk];
+      e.sst = b.f[KID_B_SST][kk]; e.sss = b.f[KID_B_SSS][kk]; e.cn = b.f[KID_B_CN][kk]; e.hi = b.f[KID_B_HI][kk]; e.od = b.f[KID_B_OD][kk];
+    }
+  }
+
+  if (PH & PH_EVOLVE) {  // IB:7081-7179
+    d.axn = b.f[KID_B_AXN][kk]; d.ayn = b.f[KID_B_AYN][kk];
+    if (!RK) { d.bxn = b.f[KID_B_BXN][kk]; d.byn = b.f[KID_B_BYN][kk]; } else { d.bxn = 0.; d.byn = 0.; }
+    const bool moves = was_alive && (t.static_berg < 0.5);
+    if (moves) {
+      const BergGeom bg{t.M, t.T, t.W, t.L, t.n_bonds};
+      if (RK) rk4_step<OLD_ORDER>(g, p, bg, e, d, tickets, err);
+      else verlet_step<OLD_ORDER>(g, p, bg, e, d, tickets, err);
+      // a berg whose cell leaves the computational domain is packed-and-deleted by send_bergs_to_other_pes on a
+      // PE without that neighbour (FW:3024-3041)
+      if (d.ine < g.isc || d.ine > g.iec || d.jne < g.jsc || d.jne > g.jec) t.alive = false;
+      b.f[KID_B_LON][kk] = d.lon; b.f[KID_B_LAT][kk] = d.lat; b.f[KID_B_UVEL][kk] = d.uvel; b.f[KID_B_VVEL][kk] = d.vvel;
+      b.f[KID_B_AXN][kk] = d.axn; b.f[KID_B_AYN][kk] = d.ayn; b.f[KID_B_BXN][kk] = d.bxn; b.f[KID_B_BYN][kk] = d.byn;
+      b.f[KID_B_XI][kk] = d.xi; b.f[KID_B_YJ][kk] = d.yj;
+      b.i[KID_BI_INE][kk] = d.ine; b.i[KID_BI_JNE][kk] = d.jne;
+      if (!RK) { b.f[KID_B_UVEL_PREV][kk] = d.uvel_prev; b.f[KID_B_VVEL_PREV][kk] = d.vvel_prev; }
+    }
+    const unsigned long long bt = __ballot(tickets != 0u);
+    if (bt) {  // rare
+      double ts = wave_sum((double)tickets);
+      if (__lane_id() == 0) unsafeAtomicAdd(scal + KID_S_NSPEEDING_TICKETS, ts);
+    }
+  }
+
+  if (PH & (PH_THERMO | PH_SPREAD)) {
+    const bool active = t.alive;
+    const Seg seg = make_seg(active ? g.idx(d.ine, d.jne) : (-1 - (int)__lane_id()));
+    if ((PH & PH_THERMO) || fl.has_fl) {
+      t.mass_scaling = b.f[KID_B_MASS_SCALING][kk];
+      t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk];
+      t.heat_density = b.f[KID_B_HEAT_DENSITY][kk];
+    } else { t.mass_scaling = b.f[KID_B_MASS_SCALING][kk]; t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk]; t.heat_density = 0.; }
+    if (fl.has_fl) {
+      t.mass_of_fl_bits = b.f[KID_B_MASS_OF_FL_BITS][kk]; t.mass_of_fl_bergy_bits = b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk];
+      t.fl_k = b.f[KID_B_FL_K][kk];
+    } else { t.mass_of_fl_bits = 0.; t.mass_of_fl_bergy_bits = 0.; t.fl_k = 0.; }
+    t.start_mass = (p.diag_mask & KID_DIAG_MELT_BY_CLASS) ? b.f[KID_B_START_MASS][kk] : 0.;
+    t.start_year = 0; t.start_day = 0.;
+    if (PH & PH_THERMO) {
+      if (OLD_ORDER || (!p.mts && !p.dem && halo)) {  // IB:2890-2894 (od is not passed there)
+        const double od_keep = e.od;
+        if (active) { interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e); env_dirty = true; }
+        if (PH & PH_INTERP) e.od = od_keep;
+      }
+      const BergThermo before = t;
+      thermodynamics(g, p, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
+      if (active) {
+        b.f[KID_B_MASS][kk] = t.M; b.f[KID_B_THICKNESS][kk] = t.T; b.f[KID_B_WIDTH][kk] = t.W; b.f[KID_B_LENGTH][kk] = t.L;
+        if (t.mass_of_bits != before.mass_of_bits) b.f[KID_B_MASS_OF_BITS][kk] = t.mass_of_bits;
+        if (fl.has_fl) {
+          b.f[KID_B_MASS_OF_FL_BITS][kk] = t.mass_of_fl_bits; b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk] = t.mass_of_fl_bergy_bits;
+          b.f[KID_B_FL_K][kk] = t.fl_k;
+          if (t.mass_scaling != before.mass_scaling) {  // converted to a footloose child (IB:3272-3289)
+            b.f[KID_B_MASS_SCALING][kk] = t.mass_scaling;
+            b.i[KID_BI_START_YEAR][kk] = t.start_year; b.f[KID_B_START_DAY][kk] = t.start_day;
+          }
+        }
+      }
+    }
+    if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
+      const bool act2 = t.alive;
+      // bergs that just melted away leave their run: rebuild the run structure so that no run loses its tail lane
+      const Seg seg2 = (__ballot(act2 != active) != 0ull) ? make_seg(act2 ? g.idx(d.ine, d.jne) : (-1 - (int)__lane_id())) : seg;
+      if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
+        spread_mass(g, p, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg2);
+      berg_diagnostics(g, p, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg2);
+    }
+  }
+
+  if (was_alive) {
+    if (!t.alive) b.i[KID_BI_ALIVE][kk] = 0;
+    if (env_dirty && fl.store_env) {
+      b.f[KID_B_UO][kk] = e.uo; b.f[KID_B_VO][kk] = e.vo; b.f[KID_B_UI][kk] = e.ui; b.f[KID_B_VI][kk] = e.vi;
+      b.f[KID_B_UA][kk] = e.ua; b.f[KID_B_VA][kk] = e.va; b.f[KID_B_SSH_X][kk] = e.ssh_x; b.f[KID_B_SSH_Y][kk] = e.ssh_y;
+      b.f[KID_B_SST][kk] = e.sst; b.f[KID_B_SSS][kk] = e.sss; b.f[KID_B_CN][kk] = e.cn; b.f[KID_B_HI][kk] = e.hi;
+      if (PH & PH_INTERP) b.f[KID_B_OD][kk] = e.od;
+    }
+  }
+  const unsigned long long be = __ballot(err != 0);
+  if (be && __lane_id() == 0) unsafeAtomicAdd(scal + KID_S_ERROR_COUNT, (double)__popcll(be));
+}
+
+// -------------------------------------------------------------------------------------------------------
+// IB:6077-6150 sum_up_spread_fields + IB:3449-3488, per cell of the computational domain
+// -------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_params p, double *__restrict__ acc,
+                                                     double *__restrict__ out, const size_t ncell) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nic = g.iec - g.isc + 1, njc = g.jec - g.jsc + 1;
+  if (t >= nic * njc) return;
+  const int i = g.isc + t % nic, j = g.jsc + t / nic;
+  const int c = g.idx(i, j), ni = g.ni;
+  const double a = g.geo[c].area, m = g.geo[c].msk;
+  const int dm = p.diag_mask;
+  auto nine = [&](int base) {
+    const double *v = acc + (size_t)base * ncell;
+#define KID_V(di, dj, s) v[(size_t)((s) - 1) * ncell + (size_t)(c + (di) + (dj) * ni)]
+    double dmda = KID_V(0, 0, 5) + (((KID_V(-1, -1, 9) + KID_V(1, 1, 1)) + (KID_V(1, -1, 7) + KID_V(-1, 1, 3)))
+                                   + ((KID_V(-1, 0, 6) + KID_V(1, 0, 4)) + (KID_V(0, -1, 8) + KID_V(0, 1, 2))));
+#undef KID_V
+    if (a > 0) dmda = dmda / a * m;
+    return dmda;
+  };
+  double su = 0., sv = 0., sa = 0.;
+  if ((dm & KID_DIAG_SPREAD_UVEL) || p.pass_fields_to_ocean_model) su = nine(KID_A_UVEL_ON_OCEAN);
+  if ((dm & KID_DIAG_SPREAD_VVEL) || p.pass_fields_to_ocean_model) sv = nine(KID_A_VVEL_ON_OCEAN);
+  if ((dm & KID_DIAG_SPREAD_AREA) || p.pass_fields_to_ocean_model) sa = dmin(nine(KID_A_AREA_ON_OCEAN), 1.0);
+  const double sm = nine(KID_A_MASS_ON_OCEAN);
+  out[(size_t)KID_O_SPREAD_MASS * ncell + c] = sm;
+  out[(size_t)KID_O_SPREAD_AREA * ncell + c] = sa;
+  out[(size_t)KID_O_SPREAD_UVEL * ncell + c] = su;
+  out[(size_t)KID_O_SPREAD_VVEL * ncell + c] = sv;
+  if ((dm & KID_DIAG_U_ICEBERG) || (dm & KID_DIAG_V_ICEBERG)) {  // IB:3450-3462
+    const double mass = acc[(size_t)KID_A_MASS * ncell + c];
+    if (dm & KID_DIAG_U_ICEBERG) acc[(size_t)KID_A_U_ICEBERG * ncell + c] = (mass > 0.) ? acc[(size_t)KID_A_U_ICEBERG * ncell + c] / mass : 0.;
+    if (dm & KID_DIAG_V_ICEBERG) acc[(size_t)KID_A_V_ICEBERG * ncell + c] = (mass > 0.) ? acc[(size_t)KID_A_V_ICEBERG * ncell + c] / mass : 0.;
+  }
+  double ustar_h = 0.;
+  if ((dm & KID_DIAG_USTAR_ICEBERG) || p.pass_fields_to_ocean_model) {  // IB:3466-3474
+    const double du = su - g.vel[c].uo, dv = sv - g.vel[c].vo;
+    const double dvo = sqrt(du * du + dv * dv);
+    const double ustar = sqrt(p.cdrag_icebergs * (dvo * dvo + p.utide_icebergs * p.utide_icebergs));
+    ustar_h = dmax(p.ustar_icebergs_bg, ustar);
+    if (sa == 0.0) ustar_h = 0.;
+  }
+  out[(size_t)KID_O_USTAR_ICEBERG * ncell + c] = ustar_h;
+  if (p.apply_thickness_cutoff_to_gridded_melt && (p.melt_cutoff >= 0.) && (sa > 0.)) {  // IB:3477-3488 (comp. domain)
+    const double ave_thickness = sm / (sa * p.rho_bergs);
+    const double ave_draft = ave_thickness * (p.rho_bergs / RHO_SEAWATER);
+    if ((g.ocean_depth[c] - ave_draft) < p.melt_cutoff) {
+      acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = 0.0; acc[(size_t)KID_A_CALVING_HFLX * ncell + c] = 0.0;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) count_alive_kernel(const int32_t *alive, long long n, unsigned long long *out) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  const bool a = (k < n) && alive[k] != 0;
+  const unsigned long long m = __ballot(a);
+  if (__lane_id() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+__global__ void __launch_bounds__(256) compact_f64_kernel(const double *src, double *dst, const int32_t *alive, const unsigned *pos, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n && alive[k]) dst[pos[k]] = src[k];
+}
+__global__ void __launch_bounds__(256) compact_i32_kernel(const int32_t *src, int32_t *dst, const int32_t *alive, const unsigned *pos, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n && alive[k]) dst[pos[k]] = src[k];
+}
+__global__ void __launch_bounds__(256) compact_i64_kernel(const int64_t *src, int64_t *dst, const int32_t *alive, const unsigned *pos, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n && alive[k]) dst[pos[k]] = src[k];
+}
+__global__ void __launch_bounds__(256) alive_to_u32_kernel(const int32_t *alive, unsigned *flag, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n) flag[k] = alive[k] ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) fill_i32_kernel(int32_t *p, int32_t v, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n) p[k] = v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+struct kid_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  kid_grid_desc gd{};
+  kid_params params{};
+  int ni = 0, nj = 0;
+  size_t ncell = 0;
+  int64_t capacity = 0, n = 0;
+  // device memory
+  double *d_static[KID_NGRID_STATIC] = {}, *d_forcing[KID_NFORCING] = {};
+  VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr;
+  double *d_acc_own = nullptr, *d_acc = nullptr;  // KID_NACC*ncell + KID_NSCALAR
+  double *d_out = nullptr;                        // KID_NOUT*ncell
+  BergPtrs bp{};
+  double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+  unsigned long long *d_count = nullptr;
+  Flags flags{0, 0, 1, 0};
+  bool have_static = false, have_forcing = false;
+  bool profile = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double berg_ms = 0., all_ms = 0.; int64_t berg_launches = 0;
+  std::string err;
+};
+
+#define KID_HIP(h, call)                                                                      \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                          \
+      return KID_EHIP;                                                                        \
+    }                                                                                         \
+  } while (0)
+
+static DevGrid dev_grid(const kid_handle *h) {
+  DevGrid g;
+  g.isd = h->gd.isd; g.ied = h->gd.ied; g.jsd = h->gd.jsd; g.jed = h->gd.jed;
+  g.isc = h->gd.isc; g.iec = h->gd.iec; g.jsc = h->gd.jsc; g.jec = h->gd.jec;
+  g.ni = h->ni; g.nj = h->nj; g.latlon = h->gd.grid_is_latlon; g.regular = h->gd.grid_is_regular; g.Lx = h->gd.Lx;
+  g.vel = h->d_vel; g.trc = h->d_trc; g.geo = h->d_geo;
+  g.dx = h->d_static[KID_G_DX]; g.dy = h->d_static[KID_G_DY]; g.ocean_depth = h->d_static[KID_G_OCEAN_DEPTH];
+  g.ssh = h->d_forcing[KID_F_SSH];
+  return g;
+}
+static int nacc_active(const kid_handle *h) {
+  const int diag_planes = KID_DIAG_MELT_BY_CLASS | KID_DIAG_FL_PARENT_MELT | KID_DIAG_FL_CHILD_MELT | KID_DIAG_MELT_BUOY |
+                          KID_DIAG_MELT_EROS | KID_DIAG_MELT_CONV | KID_DIAG_MELT_BUOY_FL | KID_DIAG_MELT_EROS_FL |
+                          KID_DIAG_MELT_CONV_FL | KID_DIAG_VIRTUAL_AREA | KID_DIAG_MASS | KID_DIAG_U_ICEBERG | KID_DIAG_V_ICEBERG;
+  return (h->params.diag_mask & diag_planes) ? KID_NACC : KID_NACC_CORE;
+}
+static int check_params(kid_handle *h, const kid_params *p) {
+  if (p->mts || p->dem) { h->err = "mts/dem (bonded DEM sub-stepping) is not implemented in this build"; return KID_EUNSUPPORTED; }
+  if (p->interactive_icebergs_on) { h->err = "interactive_icebergs_on is not implemented in this build"; return KID_EUNSUPPORTED; }
+  if (p->tidal_drift > 0.) { h->err = "tidal_drift needs FMS's random stream: not supported"; return KID_EUNSUPPORTED; }
+  if (p->time_average_weight) { h->err = "time_average_weight is not implemented"; return KID_EUNSUPPORTED; }
+  if (p->find_melt_using_spread_mass) { h->err = "find_melt_using_spread_mass is not implemented"; return KID_EUNSUPPORTED; }
+  if (p->footloose && p->displace_fl_bergs) { h->err = "footloose with displace_fl_bergs needs FMS's random stream: use displace_fl_bergs=F"; return KID_EUNSUPPORTED; }
+  if (p->Runge_not_Verlet && p->footloose) { h->err = "Runge_not_Verlet must be false to use footloose (FW:1485-1490)"; return KID_EINVAL; }
+  if (p->footloose && !p->use_operator_splitting) { h->err = "use_operator_splitting must be true to use footloose (FW:1476)"; return KID_EINVAL; }
+  return KID_OK;
+}
+
+extern "C" {
+
+const char *kid_version(void) { return "kid_hip 0.1 (gfx950)"; }
+int64_t kid_sizeof(int which) {
+  switch (which) { case 0: return (int64_t)sizeof(kid_params); case 1: return (int64_t)sizeof(kid_grid_desc);
+                   case 2: return (int64_t)sizeof(kid_berg_soa); default: return -1; }
+}
+const char *kid_last_error(const kid_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capacity, int device, kid_handle **out) {
+  if (!grid || !params || !out || capacity <= 0) return KID_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KID_ENODEV;
+  if (device < 0 || device >= ndev) return KID_ENODEV;
+  kid_handle *h = new kid_handle();
+  *out = h;  // returned even on failure so that kid_last_error() can be read; caller still destroys it
+  h->device = device;
+  KID_HIP(h, hipSetDevice(device));
+  h->gd = *grid;
+  h->ni = grid->ied - grid->isd + 1; h->nj = grid->jed - grid->jsd + 1;
+  if (h->ni < 5 || h->nj < 5 || grid->isc - grid->isd < 2 || grid->ied - grid->iec < 2 || grid->jsc - grid->jsd < 2 || grid->jed - grid->jec < 2) {
+    h->err = "grid needs a halo of at least 2 cells"; return KID_EINVAL;
+  }
+  h->ncell = (size_t)h->ni * (size_t)h->nj;
+  int rc = check_params(h, params);
+  if (rc) return rc;
+  h->params = *params;
+  h->capacity = capacity;
+  KID_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  for (int k = 0; k < KID_NGRID_STATIC; ++k) { KID_HIP(h, hipMalloc(&h->d_static[k], h->ncell * sizeof(double))); KID_HIP(h, hipMemset(h->d_static[k], 0, h->ncell * sizeof(double))); }
+  for (int k = 0; k < KID_NFORCING; ++k) { KID_HIP(h, hipMalloc(&h->d_forcing[k], h->ncell * sizeof(double))); KID_HIP(h, hipMemset(h->d_forcing[k], 0, h->ncell * sizeof(double))); }
+  KID_HIP(h, hipMalloc(&h->d_vel, h->ncell * sizeof(VelRec)));
+  KID_HIP(h, hipMalloc(&h->d_trc, h->ncell * sizeof(TrcRec)));
+  KID_HIP(h, hipMalloc(&h->d_geo, h->ncell * sizeof(GeoRec)));
+  const size_t accn = (size_t)KID_NACC * h->ncell + KID_NSCALAR;
+  KID_HIP(h, hipMalloc(&h->d_acc_own, accn * sizeof(double)));
+  KID_HIP(h, hipMemset(h->d_acc_own, 0, accn * sizeof(double)));
+  h->d_acc = h->d_acc_own;
+  KID_HIP(h, hipMalloc(&h->d_out, (size_t)KID_NOUT * h->ncell * sizeof(double)));
+  KID_HIP(h, hipMemset(h->d_out, 0, (size_t)KID_NOUT * h->ncell * sizeof(double)));
+  for (int f = 0; f < KID_NB_F64; ++f) { KID_HIP(h, hipMalloc(&h->bp.f[f], (size_t)capacity * sizeof(double))); KID_HIP(h, hipMemset(h->bp.f[f], 0, (size_t)capacity * sizeof(double))); }
+  for (int f = 0; f < KID_NB_I32; ++f) { KID_HIP(h, hipMalloc(&h->bp.i[f], (size_t)capacity * sizeof(int32_t))); KID_HIP(h, hipMemset(h->bp.i[f], 0, (size_t)capacity * sizeof(int32_t))); }
+  KID_HIP(h, hipMalloc(&h->bp.id, (size_t)capacity * sizeof(int64_t)));
+  KID_HIP(h, hipMemset(h->bp.id, 0, (size_t)capacity * sizeof(int64_t)));
+  KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
+  KID_HIP(h, hipEventCreate(&h->ev0)); KID_HIP(h, hipEventCreate(&h->ev1));
+  KID_HIP(h, hipEventCreate(&h->ev2)); KID_HIP(h, hipEventCreate(&h->ev3));
+  return KID_OK;
+}
+
+int kid_destroy(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (auto &k : h->d_static) if (k) (void)hipFree(k);
+  for (auto &k : h->d_forcing) if (k) (void)hipFree(k);
+  if (h->d_vel) (void)hipFree(h->d_vel);
+  if (h->d_trc) (void)hipFree(h->d_trc);
+  if (h->d_geo) (void)hipFree(h->d_geo);
+  if (h->d_acc_own) (void)hipFree(h->d_acc_own);
+  if (h->d_out) (void)hipFree(h->d_out);
+  for (auto &k : h->bp.f) if (k) (void)hipFree(k);
+  for (auto &k : h->bp.i) if (k) (void)hipFree(k);
+  if (h->bp.id) (void)hipFree(h->bp.id);
+  if (h->d_spare_f64) (void)hipFree(h->d_spare_f64);
+  if (h->d_pos) (void)hipFree(h->d_pos);
+  if (h->d_flag) (void)hipFree(h->d_flag);
+  if (h->d_scan_tmp) (void)hipFree(h->d_scan_tmp);
+  if (h->d_count) (void)hipFree(h->d_count);
+  for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return KID_OK;
+}
+
+int kid_set_params(kid_handle *h, const kid_params *params) {
+  if (!h || !params) return KID_EINVAL;
+  int rc = check_params(h, params);
+  if (rc) return rc;
+  h->params = *params;
+  return KID_OK;
+}
+int kid_set_stream(kid_handle *h, void *s) {
+  if (!h) return KID_EINVAL;
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return KID_OK;
+}
+int kid_sync(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  return KID_OK;
+}
+
+static int repack(kid_handle *h) {
+  GridPlanes gp;
+  for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
+  for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = h->d_forcing[k];
+  const int nb = (int)((h->ncell + 255) / 256);
+  hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, (int)h->ncell);
+  hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_vel, h->d_trc, h->ni, h->nj);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
+
+int kid_set_static_grid(kid_handle *h, const double *const fields[KID_NGRID_STATIC]) {
+  if (!h || !fields) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  for (int k = 0; k < KID_NGRID_STATIC; ++k) {
+    if (!fields[k]) { if (k == KID_G_LONC || k == KID_G_LATC) continue; h->err = "static grid field missing"; return KID_EINVAL; }
+    KID_HIP(h, hipMemcpyAsync(h->d_static[k], fields[k], h->ncell * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  h->have_static = true;
+  int rc = repack(h);
+  if (rc) return rc;
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  return KID_OK;
+}
+
+int kid_set_forcing(kid_handle *h, const double *const fields[KID_NFORCING]) {
+  if (!h || !fields) return KID_EINVAL;
+  if (!h->have_static) { h->err = "kid_set_static_grid must be called first"; return KID_EINVAL; }
+  KID_HIP(h, hipSetDevice(h->device));
+  for (int k = 0; k < KID_NFORCING; ++k) {
+    if (!fields[k]) continue;  // NULL keeps the previous plane
+    KID_HIP(h, hipMemcpyAsync(h->d_forcing[k], fields[k], h->ncell * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  h->have_forcing = true;
+  int rc = repack(h);
+  if (rc) return rc;
+  KID_HIP(h, hipStreamSynchronize(h->stream));  // the host arrays may be reused by the caller
+  return KID_OK;
+}
+
+int kid_set_forcing_device(kid_handle *h, const double *const fields[KID_NFORCING]) {
+  if (!h || !fields) return KID_EINVAL;
+  if (!h->have_static) { h->err = "kid_set_static_grid must be called first"; return KID_EINVAL; }
+  KID_HIP(h, hipSetDevice(h->device));
+  for (int k = 0; k < KID_NFORCING; ++k) {
+    if (!fields[k]) continue;
+    KID_HIP(h, hipMemcpyAsync(h->d_forcing[k], fields[k], h->ncell * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  h->have_forcing = true;
+  return repack(h);
+}
+
+int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
+  if (!h || !host || host->n < 0) return KID_EINVAL;
+  if (host->n > h->capacity) { h->err = "more bergs than capacity"; return KID_ECAPACITY; }
+  KID_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)host->n;
+  bool any_static = false, any_fl = false;
+  for (int f = 0; f < KID_NB_F64; ++f) {
+    if (host->f64[f]) KID_HIP(h, hipMemcpyAsync(h->bp.f[f], host->f64[f], n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    else KID_HIP(h, hipMemsetAsync(h->bp.f[f], 0, n * sizeof(double), h->stream));
+  }
+  for (int f = 0; f < KID_NB_I32; ++f) {
+    if (host->i32[f]) KID_HIP(h, hipMemcpyAsync(h->bp.i[f], host->i32[f], n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    else if (f == KID_BI_ALIVE) { if (n) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[f], 1, (long long)n); }
+    else KID_HIP(h, hipMemsetAsync(h->bp.i[f], 0, n * sizeof(int32_t), h->stream));
+  }
+  if (host->id) KID_HIP(h, hipMemcpyAsync(h->bp.id, host->id, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  else KID_HIP(h, hipMemsetAsync(h->bp.id, 0, n * sizeof(int64_t), h->stream));
+  // which optional per-berg fields can matter at all (avoids streaming all-zero arrays through the kernel)
+  for (size_t k = 0; k < n; ++k) {
+    if (host->f64[KID_B_STATIC_BERG] && host->f64[KID_B_STATIC_BERG][k] != 0.) any_static = true;
+    if (host->f64[KID_B_HALO_BERG] && host->f64[KID_B_HALO_BERG][k] != 0.) any_static = true;
+    if (host->f64[KID_B_MASS_OF_FL_BITS] && host->f64[KID_B_MASS_OF_FL_BITS][k] != 0.) any_fl = true;
+    if (host->f64[KID_B_MASS_OF_FL_BERGY_BITS] && host->f64[KID_B_MASS_OF_FL_BERGY_BITS][k] != 0.) any_fl = true;
+    if (host->f64[KID_B_FL_K] && host->f64[KID_B_FL_K][k] != 0.) any_fl = true;
+  }
+  h->flags.has_static = any_static ? 1 : 0;
+  h->flags.has_fl = (any_fl || h->params.footloose) ? 1 : 0;
+  h->n = host->n;
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  return KID_OK;
+}
+
+int kid_download_bergs(kid_handle *h, kid_berg_soa *host) {
+  if (!h || !host) return KID_EINVAL;
+  if (host->n < h->n) { h->err = "host SoA too small"; return KID_EINVAL; }
+  KID_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->n;
+  for (int f = 0; f < KID_NB_F64; ++f)
+    if (host->f64[f]) KID_HIP(h, hipMemcpyAsync(host->f64[f], h->bp.f[f], n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  for (int f = 0; f < KID_NB_I32; ++f)
+    if (host->i32[f]) KID_HIP(h, hipMemcpyAsync(host->i32[f], h->bp.i[f], n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (host->id) KID_HIP(h, hipMemcpyAsync(host->id, h->bp.id, n * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  host->n = h->n;
+  return KID_OK;
+}
+
+int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  if (n_slots) *n_slots = h->n;
+  if (n_alive) {
+    unsigned long long cnt = 0;
+    KID_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(cnt), h->stream));
+    if (h->n > 0) hipLaunchKernelGGL(count_alive_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], (long long)h->n, h->d_count);
+    KID_HIP(h, hipMemcpyAsync(&cnt, h->d_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+    KID_HIP(h, hipStreamSynchronize(h->stream));
+    *n_alive = (int64_t)cnt;
+  }
+  return KID_OK;
+}
+
+int kid_compact_bergs(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  if (h->n == 0) return KID_OK;
+  const long long n = h->n;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (!h->d_spare_f64) {
+    KID_HIP(h, hipMalloc(&h->d_spare_f64, (size_t)h->capacity * sizeof(double)));
+    KID_HIP(h, hipMalloc(&h->d_pos, (size_t)h->capacity * sizeof(unsigned)));
+    KID_HIP(h, hipMalloc(&h->d_flag, (size_t)h->capacity * sizeof(unsigned)));
+    size_t tmp = 0;
+    KID_HIP(h, rocprim::exclusive_scan(nullptr, tmp, h->d_flag, h->d_pos, 0u, (size_t)h->capacity, rocprim::plus<unsigned>(), h->stream));
+    h->scan_tmp_bytes = tmp;
+    KID_HIP(h, hipMalloc(&h->d_scan_tmp, tmp));
+  }
+  hipLaunchKernelGGL(alive_to_u32_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], h->d_flag, n);
+  size_t tmp = h->scan_tmp_bytes;
+  KID_HIP(h, rocprim::exclusive_scan(h->d_scan_tmp, tmp, h->d_flag, h->d_pos, 0u, (size_t)n, rocprim::plus<unsigned>(), h->stream));
+  int64_t n_alive = 0;
+  int rc = kid_num_bergs(h, nullptr, &n_alive);
+  if (rc) return rc;
+  for (int f = 0; f < KID_NB_F64; ++f) {
+    hipLaunchKernelGGL(compact_f64_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.f[f], h->d_spare_f64, h->bp.i[KID_BI_ALIVE], h->d_pos, n);
+    std::swap(h->bp.f[f], h->d_spare_f64);
+  }
+  {
+    int64_t *spare = (int64_t *)h->d_spare_f64;  // same element size
+    hipLaunchKernelGGL(compact_i64_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.id, spare, h->bp.i[KID_BI_ALIVE], h->d_pos, n);
+    double *old = (double *)h->bp.id; h->bp.id = spare; h->d_spare_f64 = old;
+  }
+  for (int f = 0; f < KID_NB_I32; ++f) {
+    if (f == KID_BI_ALIVE) continue;
+    int32_t *spare = (int32_t *)h->d_flag;  // reuse the flag buffer as int32 spare
+    hipLaunchKernelGGL(compact_i32_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[f], spare, h->bp.i[KID_BI_ALIVE], h->d_pos, n);
+    unsigned *old = (unsigned *)h->bp.i[f]; h->bp.i[f] = spare; h->d_flag = old;
+  }
+  if (n_alive > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n_alive + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], 1, (long long)n_alive);
+  KID_HIP(h, hipGetLastError());
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  h->n = n_alive;
+  return KID_OK;
+}
+
+int kid_zero_accumulators(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  const size_t planes = (size_t)nacc_active(h);
+  KID_HIP(h, hipMemsetAsync(h->d_acc, 0, planes * h->ncell * sizeof(double), h->stream));
+  // scalars other than the running totals are per-step; the reference keeps running totals on `bergs`
+  // (net_heat_to_ocean, nbergs_melted, ...): the caller reads increments, so zero them too.
+  KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_NACC * h->ncell, 0, KID_NSCALAR * sizeof(double), h->stream));
+  return KID_OK;
+}
+
+}  // extern "C"
+
+template <unsigned PH>
+static int launch_berg(kid_handle *h) {
+  if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
+  if (h->n == 0) return KID_OK;
+  const DevGrid g = dev_grid(h);
+  const unsigned nb = (unsigned)((h->n + 255) / 256);
+  const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profile) {
+    KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1));
+    KID_HIP(h, hipEventRecord(e0, h->stream));
+  }
+#define KID_LAUNCH(RKV, OLDV) hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH>), dim3(nb), dim3(256), 0, h->stream, g, h->params, h->bp, (long long)h->n, h->d_acc, h->ncell, h->flags)
+  if (rk && old) KID_LAUNCH(true, true);
+  else if (rk && !old) KID_LAUNCH(true, false);
+  else if (!rk && old) KID_LAUNCH(false, true);
+  else KID_LAUNCH(false, false);
+#undef KID_LAUNCH
+  KID_HIP(h, hipGetLastError());
+  if (h->profile) { KID_HIP(h, hipEventRecord(e1, h->stream)); h->pending.emplace_back(e0, e1); h->berg_launches++; }
+  return KID_OK;
+}
+
+extern "C" {
+
+int kid_interp_gridded_fields_to_bergs(kid_handle *h) { if (!h) return KID_EINVAL; KID_HIP(h, hipSetDevice(h->device)); return launch_berg<PH_INTERP>(h); }
+int kid_evolve_icebergs(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  if (h->params.static_icebergs) return KID_OK;  // IB:5428
+  return launch_berg<PH_EVOLVE>(h);
+}
+int kid_thermodynamics(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  // IB:2872-2873
+  KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_A_UVEL_ON_OCEAN * h->ncell, 0, 18 * h->ncell * sizeof(double), h->stream));
+  return launch_berg<PH_THERMO>(h);
+}
+int kid_footloose_calving(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  if (!h->params.footloose) return KID_OK;
+  h->err = "footloose_calving kernel is not built yet";
+  return KID_EUNSUPPORTED;
+}
+
+static int launch_gather(kid_handle *h) {
+  const DevGrid g = dev_grid(h);
+  const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
+int kid_create_gridded_icebergs_fields(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_A_MASS_ON_OCEAN * h->ncell, 0, 36 * h->ncell * sizeof(double), h->stream));  // IB:4984-4987
+  int rc = launch_berg<PH_SPREAD>(h);
+  if (rc) return rc;
+  return launch_gather(h);
+}
+
+int kid_step_local(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  if (h->profile) KID_HIP(h, hipEventRecord(h->ev2, h->stream));
+  int rc = kid_zero_accumulators(h);
+  if (rc) return rc;
+  const kid_params &p = h->params;
+  if (p.footloose) { h->err = "fused step with footloose is not built yet"; return KID_EUNSUPPORTED; }
+  if (p.old_interp_flds_order) {
+    if (p.static_icebergs) rc = launch_berg<PH_THERMO | PH_SPREAD>(h);
+    else rc = launch_berg<PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
+  } else {
+    // IB:5423: interpolate, evolve; IB:5473: interpolate again at the new position, then thermodynamics
+    rc = p.static_icebergs ? launch_berg<PH_INTERP>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h);
+    if (rc) return rc;
+    rc = launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
+  }
+  return rc;
+}
+int kid_step_gather(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  int rc = launch_gather(h);
+  if (rc) return rc;
+  if (h->profile) {
+    KID_HIP(h, hipEventRecord(h->ev3, h->stream));
+    KID_HIP(h, hipEventSynchronize(h->ev3));
+    float ms = 0.f;
+    KID_HIP(h, hipEventElapsedTime(&ms, h->ev2, h->ev3));
+    h->all_ms += ms;
+    for (auto &pe : h->pending) {
+      KID_HIP(h, hipEventElapsedTime(&ms, pe.first, pe.second));
+      h->berg_ms += ms;
+      (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second);
+    }
+    h->pending.clear();
+  }
+  return KID_OK;
+}
+int kid_run_step(kid_handle *h, int nsteps) {
+  if (!h || nsteps < 0) return KID_EINVAL;
+  for (int s = 0; s < nsteps; ++s) {
+    int rc = kid_step_local(h);
+    if (rc) return rc;
+    rc = kid_step_gather(h);
+    if (rc) return rc;
+  }
+  return KID_OK;
+}
+
+int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalars) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  if (acc) KID_HIP(h, hipMemcpyAsync(acc, h->d_acc, (size_t)KID_NACC * h->ncell * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out) KID_HIP(h, hipMemcpyAsync(out, h->d_out, (size_t)KID_NOUT * h->ncell * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (scalars) KID_HIP(h, hipMemcpyAsync(scalars, h->d_acc + (size_t)KID_NACC * h->ncell, KID_NSCALAR * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  if (scalars) {
+    int64_t alive = 0;
+    int rc = kid_num_bergs(h, nullptr, &alive);
+    if (rc) return rc;
+    scalars[KID_S_NBERGS_ALIVE] = (double)alive;
+  }
+  return KID_OK;
+}
+int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count) {
+  if (!h || !dev_ptr || !count) return KID_EINVAL;
+  *dev_ptr = h->d_acc;
+  *count = (int64_t)((size_t)KID_NACC * h->ncell + KID_NSCALAR);
+  return KID_OK;
+}
+int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count) {
+  if (!h) return KID_EINVAL;
+  if (!dev_ptr) { h->d_acc = h->d_acc_own; return KID_OK; }
+  if (count < (int64_t)((size_t)KID_NACC * h->ncell + KID_NSCALAR)) { h->err = "accumulator buffer too small"; return KID_EINVAL; }
+  h->d_acc = (double *)dev_ptr;
+  return KID_OK;
+}
+
+int kid_profile_enable(kid_handle *h, int on) {
+  if (!h) return KID_EINVAL;
+  h->profile = on != 0;
+  h->berg_ms = 0.; h->all_ms = 0.; h->berg_launches = 0;
+  return KID_OK;
+}
+int kid_profile_get(kid_handle *h, double *berg_ms, int64_t *launches, double *all_ms) {
+  if (!h) return KID_EINVAL;
+  if (berg_ms) *berg_ms = h->berg_ms;
+  if (launches) *launches = h->berg_launches;
+  if (all_ms) *all_ms = h->all_ms;
+  return KID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's `ice_bergs` surface for the evolve-loop path.
+
+The reference host is Fortran (icebergs_init / icebergs_run, src/icebergs.F90:92-178, 5074-5887) and the
+Fortran binding lives in icebergs_amd/fortran/.  This module is the same thin host layer in Python, used by
+the tests, bench.py and the multi-GPU driver: it owns no numerics, it only moves arrays across the C ABI
+(include/kid.h) and calls the phases in the order icebergs_run does (IB:5423-5512).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from . import types as T
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Icebergs:
+    """One handle == one `type(icebergs)` container bound to one GPU (and one HIP stream)."""
+
+    def __init__(self, grid, params, capacity, device=0):
+        """icebergs_init (IB:92-178): grid + parameters -> device-resident state."""
+        self.lib = _lib.load()
+        self.grid = grid
+        self.params = params
+        d = grid["desc"]
+        self.ni, self.nj = d.ied - d.isd + 1, d.jed - d.jsd + 1
+        self.ncell = self.ni * self.nj
+        self.h = C.c_void_p()
+        rc = self.lib.kid_create(C.byref(d), C.byref(params), int(capacity), int(device), C.byref(self.h))
+        if rc != 0:
+            msg = self.lib.kid_last_error(self.h).decode() if self.h else "kid_create failed"
+            if self.h:
+                self.lib.kid_destroy(self.h)
+                self.h = None
+            raise _lib.KidError("kid_create: rc=%d %s" % (rc, msg))
+        arr = (C.POINTER(C.c_double) * T.ENUMS["KID_NGRID_STATIC"])()
+        keep = []
+        for k, name in enumerate(T.GRID_STATIC_NAMES):
+            a = np.ascontiguousarray(grid["static"][name], dtype=np.float64)
+            assert a.shape == (self.nj, self.ni), (name, a.shape)
+            keep.append(a)
+            arr[k] = _dp(a)
+        self._check(self.lib.kid_set_static_grid(self.h, arr), "kid_set_static_grid")
+        self.set_forcing(grid["forcing"])
+        self.acc = np.zeros((T.NACC, self.nj, self.ni))
+        self.out = np.zeros((T.NOUT, self.nj, self.ni))
+        self.scalars = np.zeros(T.NSCALAR)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _lib.KidError("%s: rc=%d %s" % (what, rc, self.lib.kid_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- forcing (what icebergs_run's ingest block leaves in grd%*, IB:5236-5383) ----
+    def set_forcing(self, forcing):
+        arr = (C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"])()
+        keep = []
+        for k, name in enumerate(T.FORCING_NAMES):
+            a = np.ascontiguousarray(forcing[name], dtype=np.float64)
+            assert a.shape == (self.nj, self.ni), (name, a.shape)
+            keep.append(a)
+            arr[k] = _dp(a)
+        self._check(self.lib.kid_set_forcing(self.h, arr), "kid_set_forcing")
+
+    def set_forcing_device(self, dev_ptrs):
+        """dev_ptrs: KID_NFORCING device addresses (0 keeps a plane); asynchronous on the handle's stream."""
+        arr = (C.c_void_p * T.ENUMS["KID_NFORCING"])(*[C.c_void_p(int(x)) if x else None for x in dev_ptrs])
+        self._check(self.lib.kid_set_forcing_device(self.h, arr), "kid_set_forcing_device")
+
+    def set_params(self, params):
+        self.params = params
+        self._check(self.lib.kid_set_params(self.h, C.byref(params)), "kid_set_params")
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.kid_set_stream(self.h, C.c_void_p(stream_ptr)), "kid_set_stream")
+
+    # ---- berg population ----
+    @staticmethod
+    def _soa(bergs, n=None):
+        s = T.BergSoA()
+        s.n = len(bergs["lon"]) if n is None else n
+        for k, name in enumerate(T.BERG_F64_NAMES):
+            a = bergs[name]
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+            s.f64[k] = _dp(a)
+        for k, name in enumerate(T.BERG_I32_NAMES):
+            a = bergs[name]
+            assert a.dtype == np.int32 and a.flags.c_contiguous
+            s.i32[k] = a.ctypes.data_as(C.POINTER(C.c_int32))
+        s.id = bergs["id"].ctypes.data_as(C.POINTER(C.c_int64))
+        return s
+
+    def upload_bergs(self, bergs):
+        s = self._soa(bergs)
+        self._check(self.lib.kid_upload_bergs(self.h, C.byref(s)), "kid_upload_bergs")
+
+    def num_bergs(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.kid_num_bergs(self.h, C.byref(a), C.byref(b)), "kid_num_bergs")
+        return a.value, b.value
+
+    def download_bergs(self):
+        from .synthetic import empty_bergs
+        n, _ = self.num_bergs()
+        b = empty_bergs(n)
+        s = self._soa(b)
+        self._check(self.lib.kid_download_bergs(self.h, C.byref(s)), "kid_download_bergs")
+        return b
+
+    def compact(self):
+        self._check(self.lib.kid_compact_bergs(self.h), "kid_compact_bergs")
+
+    # ---- icebergs_run, the hot-path part (IB:5423-5512) ----
+    def run(self, nsteps=1):
+        """Fused path: per step one per-berg launch (evolve + thermodynamics + spreading) and one gather."""
+        self._check(self.lib.kid_run_step(self.h, int(nsteps)), "kid_run_step")
+
+    def step_local(self):
+        self._check(self.lib.kid_step_local(self.h), "kid_step_local")
+
+    def step_gather(self):
+        self._check(self.lib.kid_step_gather(self.h), "kid_step_gather")
+
+    def run_phases(self, nsteps=1):
+        """Phase-by-phase path: exactly the reference's call sequence inside icebergs_run."""
+        p = self.params
+        for _ in range(nsteps):
+            self._check(self.lib.kid_zero_accumulators(self.h), "kid_zero_accumulators")          # IB:5125-5156
+            if not p.mts and not p.old_interp_flds_order:
+                self._check(self.lib.kid_interp_gridded_fields_to_bergs(self.h), "interp")          # IB:5423
+            self._check(self.lib.kid_evolve_icebergs(self.h), "kid_evolve_icebergs")               # IB:5433
+            if p.footloose:
+                self._check(self.lib.kid_footloose_calving(self.h), "kid_footloose_calving")       # IB:5453
+            if not p.old_interp_flds_order:
+                self._check(self.lib.kid_interp_gridded_fields_to_bergs(self.h), "interp")          # IB:5473
+            self._check(self.lib.kid_thermodynamics(self.h), "kid_thermodynamics")                 # IB:5505
+            self._check(self.lib.kid_create_gridded_icebergs_fields(self.h), "kid_create_gridded") # IB:5512
+
+    def fetch(self):
+        self._check(self.lib.kid_get_accumulators(self.h, _dp(self.acc), _dp(self.out), _dp(self.scalars)), "kid_get_accumulators")
+        return self.acc, self.out, self.scalars
+
+    def sync(self):
+        self._check(self.lib.kid_sync(self.h), "kid_sync")
+
+    def accum_device_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.kid_accum_device_ptr(self.h, C.byref(p), C.byref(n)), "kid_accum_device_ptr")
+        return p.value, n.value
+
+    def bind_accum_buffer(self, ptr, count):
+        self._check(self.lib.kid_bind_accum_buffer(self.h, C.c_void_p(ptr), int(count)), "kid_bind_accum_buffer")
+
+    def profile(self, on=True):
+        self._check(self.lib.kid_profile_enable(self.h, 1 if on else 0), "kid_profile_enable")
+
+    def profile_get(self):
+        a, n, b = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.kid_profile_get(self.h, C.byref(a), C.byref(n), C.byref(b)), "kid_profile_get")
+        return a.value, n.value, b.value

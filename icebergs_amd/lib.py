@@ -1,0 +1,81 @@
+"""ctypes loader of libkid_hip.so, the C-ABI product library (include/kid.h).
+
+There is no CPU fallback: if the shared object is missing or was not built, ``load()`` raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import types as T
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SO_PATH = os.path.join(_CSRC, "libkid_hip.so")
+
+# every symbol include/kid.h declares (checked by tests/test_abi.py without a GPU)
+SYMBOLS = [
+    "kid_create", "kid_destroy", "kid_set_params", "kid_set_stream", "kid_sync", "kid_last_error", "kid_version",
+    "kid_sizeof", "kid_set_static_grid", "kid_set_forcing", "kid_set_forcing_device", "kid_upload_bergs", "kid_download_bergs",
+    "kid_num_bergs", "kid_compact_bergs", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
+    "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
+    "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
+    "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
+]
+
+
+class KidError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libkid_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", _CSRC] + ([] if verbose else ["-s"]), check=True)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise KidError("libkid_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                       "there is no CPU fallback")
+    lib = C.CDLL(SO_PATH)
+    H = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    lib.kid_version.restype = C.c_char_p
+    lib.kid_last_error.restype = C.c_char_p
+    lib.kid_last_error.argtypes = [H]
+    lib.kid_sizeof.restype = C.c_int64
+    lib.kid_sizeof.argtypes = [C.c_int]
+    lib.kid_create.argtypes = [C.POINTER(T.GridDesc), C.POINTER(T.Params), C.c_int64, C.c_int, C.POINTER(H)]
+    lib.kid_destroy.argtypes = [H]
+    lib.kid_set_params.argtypes = [H, C.POINTER(T.Params)]
+    lib.kid_set_stream.argtypes = [H, C.c_void_p]
+    lib.kid_sync.argtypes = [H]
+    lib.kid_set_static_grid.argtypes = [H, C.POINTER(dp)]
+    lib.kid_set_forcing.argtypes = [H, C.POINTER(dp)]
+    lib.kid_set_forcing_device.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
+    lib.kid_download_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
+    lib.kid_num_bergs.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    for name in ("kid_compact_bergs", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
+                 "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics",
+                 "kid_create_gridded_icebergs_fields", "kid_step_local", "kid_step_gather"):
+        getattr(lib, name).argtypes = [H]
+    lib.kid_run_step.argtypes = [H, C.c_int]
+    lib.kid_get_accumulators.argtypes = [H, dp, dp, dp]
+    lib.kid_accum_device_ptr.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.kid_bind_accum_buffer.argtypes = [H, C.c_void_p, C.c_int64]
+    lib.kid_profile_enable.argtypes = [H, C.c_int]
+    lib.kid_profile_get.argtypes = [H, dp, C.POINTER(C.c_int64), dp]
+    for name in SYMBOLS:
+        if name not in ("kid_version", "kid_last_error", "kid_sizeof"):
+            getattr(lib, name).restype = C.c_int
+    assert lib.kid_sizeof(0) == C.sizeof(T.Params), "kid_params layout mismatch between header and library"
+    assert lib.kid_sizeof(1) == C.sizeof(T.GridDesc)
+    assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
+    _lib = lib
+    return lib

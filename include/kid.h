@@ -1,0 +1,101 @@
+/* kid.h -- C ABI of libkid_hip.so: the MI355X (gfx950) implementation of the NOAA-GFDL/icebergs evolve loop.
+ *
+ * Drop-in boundary.  Each entry point replaces one `subroutine f(bergs)` call site
+ * inside icebergs_run() of /root/reference/src/icebergs.F90; the Fortran host keeps icebergs_init() /
+ * icebergs_run() and its derived types, flattens the per-cell linked lists into the structure of arrays of
+ * kid_types.h in reference traversal order, and calls these through the ISO_C_BINDING module
+ * icebergs_amd/fortran/kid_hip_binding.F90 (see INTEGRATION.md for the glue a maintainer adds).
+ *
+ *   reference call site (icebergs.F90)                     entry point
+ *   -----------------------------------------------------  --------------------------------------------
+ *   ice_bergs_framework_init, grid copy   FW:1021-1094     kid_create + kid_set_static_grid
+ *   forcing ingest result (grd%uo ... )   IB:5236-5383     kid_set_forcing
+ *   accumulator zeroing                   IB:5125-5156     kid_zero_accumulators
+ *   interp_gridded_fields_to_bergs        IB:5423, 5473    kid_interp_gridded_fields_to_bergs
+ *   evolve_icebergs                       IB:5433          kid_evolve_icebergs
+ *   footloose_calving                     IB:5453          kid_footloose_calving
+ *   thermodynamics                        IB:5505          kid_thermodynamics
+ *   create_gridded_icebergs_fields        IB:5512          kid_create_gridded_icebergs_fields
+ *   (all of the above, one coupling step)                  kid_run_step / kid_step_local + kid_step_gather
+ *
+ * Conventions: every function returns 0 on success and a negative KID_E* code on failure (the Fortran shim
+ * turns non-zero into error_mesg(...,FATAL), the reference's abort-on-error convention, e.g. IB:3207).
+ * Host arrays are caller-owned, column-major fp64 / int32 as Fortran owns them; the library owns device
+ * memory only.  One handle <-> one HIP device and one stream; handles are not thread-safe (the reference is
+ * single-threaded per rank and non-reentrant, IB:5110).  There is no CPU fallback: if no gfx950 device can be
+ * used, kid_create fails.
+ */
+#ifndef KID_H
+#define KID_H
+#include "kid_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kid_handle kid_handle;
+
+enum {
+  KID_OK = 0,
+  KID_EINVAL = -1,     /* bad argument / shape mismatch                         */
+  KID_EHIP = -2,       /* a HIP runtime call failed (see kid_last_error)        */
+  KID_ENODEV = -3,     /* no usable GPU                                         */
+  KID_ECAPACITY = -4,  /* more bergs than the handle's capacity                 */
+  KID_EUNSUPPORTED = -5 /* a switch combination this build does not implement   */
+};
+
+/* ---- lifetime ---- */
+int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capacity, int device,
+               kid_handle **out);
+int kid_destroy(kid_handle *h);
+int kid_set_params(kid_handle *h, const kid_params *params);
+/* Launch on an existing hipStream_t (e.g. PyTorch's current stream); NULL = the handle's own stream. */
+int kid_set_stream(kid_handle *h, void *hip_stream);
+int kid_sync(kid_handle *h);
+const char *kid_last_error(const kid_handle *h);
+const char *kid_version(void);
+int64_t kid_sizeof(int which); /* 0 kid_params, 1 kid_grid_desc, 2 kid_berg_soa: ABI layout check */
+
+/* ---- grid and forcing (host pointers; KID_G_* / KID_F_* order) ---- */
+int kid_set_static_grid(kid_handle *h, const double *const fields[KID_NGRID_STATIC]);
+int kid_set_forcing(kid_handle *h, const double *const fields[KID_NFORCING]);
+/* Same, but the planes already live in device memory (e.g. an ocean model on the same GPU): device-to-device
+ * copy + the per-cell prepass, asynchronous on the handle's stream. */
+int kid_set_forcing_device(kid_handle *h, const double *const dev_fields[KID_NFORCING]);
+
+/* ---- berg population ---- */
+int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host);        /* sets the population (n <= capacity) */
+int kid_download_bergs(kid_handle *h, kid_berg_soa *host);            /* host->n must be >= kid_num_bergs slots */
+int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive); /* slots include dead bergs until compaction */
+int kid_compact_bergs(kid_handle *h);                                 /* drop melted / departed bergs, keep order */
+
+/* ---- the hot path, phase by phase (same order as icebergs_run, IB:5423-5512) ---- */
+int kid_zero_accumulators(kid_handle *h);
+int kid_interp_gridded_fields_to_bergs(kid_handle *h);
+int kid_evolve_icebergs(kid_handle *h);
+int kid_footloose_calving(kid_handle *h);
+int kid_thermodynamics(kid_handle *h);
+int kid_create_gridded_icebergs_fields(kid_handle *h);
+
+/* ---- the hot path, fused: one launch does evolve + thermodynamics + mass spreading per berg ---- */
+int kid_step_local(kid_handle *h);   /* zero accumulators, per-berg kernel(s); accumulators hold LOCAL sums */
+int kid_step_gather(kid_handle *h);  /* 9-point gather + derived fields (after the cross-GPU all-reduce) */
+int kid_run_step(kid_handle *h, int nsteps); /* nsteps x (kid_step_local; kid_step_gather) */
+
+/* ---- results ---- */
+/* acc: KID_NACC fields, out: KID_NOUT fields, each (ied-isd+1)*(jed-jsd+1); scalars: KID_NSCALAR. NULL skips. */
+int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalars);
+/* Device view of the accumulator block for RCCL: KID_NACC*ncell + KID_NSCALAR contiguous doubles. */
+int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count);
+/* Use caller-owned device memory (e.g. a torch tensor) for the accumulator block instead. */
+int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count);
+
+/* ---- measurement: HIP-event timing of the per-berg kernel on the launch stream ---- */
+int kid_profile_enable(kid_handle *h, int on);
+int kid_profile_get(kid_handle *h, double *berg_kernel_ms_total, int64_t *berg_kernel_launches,
+                    double *all_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KID_H */

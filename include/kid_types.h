@@ -73,7 +73,10 @@ typedef struct kid_berg_soa {
   int64_t *id;               /* FW:325 integer(kind=8) :: id */
 } kid_berg_soa;
 
-/* ---- per-cell accumulators written by the hot path (zeroed at IB:5125-5156) ---- */
+/* ---- per-cell accumulators written by the hot path (zeroed at IB:5125-5156) ----
+ * Planes that are always live come first (KID_NACC_CORE of them): that prefix is what gets zeroed each step
+ * and what the multi-GPU all-reduce carries; the diagnostics-only planes (guarded by `id_*>0` in the
+ * reference) follow and join the reduction only when kid_params.diag_mask asks for them. */
 enum {
   KID_A_FLOATING_MELT = 0, /* IB:3117 */
   KID_A_BERG_MELT,         /* IB:3133 */
@@ -82,16 +85,18 @@ enum {
   KID_A_BERGY_MELT,        /* IB:3139 */
   KID_A_FL_BITS_MELT,      /* IB:3142 */
   KID_A_FL_BITS_SRC,       /* IB:3287, IB:2642 */
-  KID_A_MELT_BUOY, KID_A_MELT_EROS, KID_A_MELT_CONV,             /* IB:3154-3165 */
-  KID_A_MELT_BUOY_FL, KID_A_MELT_EROS_FL, KID_A_MELT_CONV_FL,    /* IB:3167-3198 */
-  KID_A_FL_PARENT_MELT, KID_A_FL_CHILD_MELT,                     /* IB:3146-3153, 3183-3186 */
-  KID_A_MASS, KID_A_BERGY_MASS, KID_A_FL_BITS_MASS, KID_A_FL_BERGY_BITS_MASS, /* IB:5050-5070 */
-  KID_A_VIRTUAL_AREA, KID_A_U_ICEBERG, KID_A_V_ICEBERG,          /* IB:5026-5058 */
+  KID_A_BERGY_MASS, KID_A_FL_BITS_MASS, KID_A_FL_BERGY_BITS_MASS, /* IB:5060-5070 (on with add_weight_to_ocean) */
   KID_A_MASS_ON_OCEAN,                       /* 9 consecutive slots, IB:4088 */
   KID_A_AREA_ON_OCEAN = KID_A_MASS_ON_OCEAN + 9,
   KID_A_UVEL_ON_OCEAN = KID_A_AREA_ON_OCEAN + 9,
   KID_A_VVEL_ON_OCEAN = KID_A_UVEL_ON_OCEAN + 9,
-  KID_A_MELT_BY_CLASS = KID_A_VVEL_ON_OCEAN + 9, /* 10 classes, IB:3125 */
+  KID_NACC_CORE = KID_A_VVEL_ON_OCEAN + 9,
+  /* diagnostics-only planes */
+  KID_A_MASS = KID_NACC_CORE, KID_A_VIRTUAL_AREA, KID_A_U_ICEBERG, KID_A_V_ICEBERG, /* IB:5026-5058 */
+  KID_A_MELT_BUOY, KID_A_MELT_EROS, KID_A_MELT_CONV,             /* IB:3154-3165 */
+  KID_A_MELT_BUOY_FL, KID_A_MELT_EROS_FL, KID_A_MELT_CONV_FL,    /* IB:3167-3198 */
+  KID_A_FL_PARENT_MELT, KID_A_FL_CHILD_MELT,                     /* IB:3146-3153, 3183-3186 */
+  KID_A_MELT_BY_CLASS,                       /* 10 classes, IB:3125 */
   KID_NACC = KID_A_MELT_BY_CLASS + 10
 };
 /* ---- derived gridded outputs of create_gridded_icebergs_fields (IB:3390-3489) ---- */

@@ -1,0 +1,82 @@
+"""Shared helpers of the parity tests: run the same seeded inputs through the CPU oracle and through the HIP
+library (via the C ABI) and compare with the tolerances of SURVEY.md section 8d."""
+import numpy as np
+
+from icebergs_amd import synthetic as S
+
+TRAJ_FIELDS = ["lon", "lat", "uvel", "vvel", "axn", "ayn", "bxn", "byn", "xi", "yj"]
+SIZE_FIELDS = ["mass", "thickness", "width", "length", "mass_of_bits", "mass_scaling", "mass_of_fl_bits",
+               "mass_of_fl_bergy_bits", "fl_k"]
+ENV_FIELDS = ["uo", "vo", "ui", "vi", "ua", "va", "ssh_x", "ssh_y", "sst", "sss", "cn", "hi"]
+TOL_TRAJ = 1.0e-10   # BASELINE.json: trajectories within 1e-10 relative of the CPU reference
+TOL_SIZE = 1.0e-10   # berg mass/size
+TOL_GRID = 1.0e-9    # per-cell fields, relative to the field max (summation order)
+
+
+def rel_err(a, b):
+    scale = np.max(np.abs(b)) if b.size else 0.0
+    if scale == 0.0:
+        return float(np.max(np.abs(a))) if a.size else 0.0
+    return float(np.max(np.abs(a - b)) / scale)
+
+
+def run_oracle(grid, params, bergs, nsteps):
+    import oracle_lib
+    o = oracle_lib.Oracle(grid, params)
+    b = S.copy_bergs(bergs)
+    o.run_step(b, nsteps)
+    return b, o.acc.copy(), o.out.copy(), o.scalars.copy()
+
+
+def run_hip(grid, params, bergs, nsteps, mode="fused", device=0):
+    from icebergs_amd.framework import Icebergs
+    ib = Icebergs(grid, params, capacity=max(len(bergs["lon"]), 1), device=device)
+    try:
+        ib.upload_bergs(bergs)
+        if mode == "fused":
+            ib.run(nsteps)
+        else:
+            ib.run_phases(nsteps)
+        acc, out, scal = ib.fetch()
+        b = ib.download_bergs()
+        return b, acc.copy(), out.copy(), scal.copy()
+    finally:
+        ib.close()
+
+
+def compare(ref, got, label=""):
+    rb, racc, rout, rscal = ref
+    gb, gacc, gout, gscal = got
+    report = {}
+    assert np.array_equal(rb["alive"], gb["alive"]), label + ": set of surviving bergs differs"
+    alive = rb["alive"] != 0
+    assert np.array_equal(rb["ine"][alive], gb["ine"][alive]), label + ": ine differs"
+    assert np.array_equal(rb["jne"][alive], gb["jne"][alive]), label + ": jne differs"
+    for f in TRAJ_FIELDS:
+        e = rel_err(gb[f][alive], rb[f][alive])
+        report[f] = e
+        assert e <= TOL_TRAJ, "%s: %s rel err %.3e > %.1e" % (label, f, e, TOL_TRAJ)
+    for f in SIZE_FIELDS:
+        e = rel_err(gb[f][alive], rb[f][alive])
+        report[f] = e
+        assert e <= TOL_SIZE, "%s: %s rel err %.3e > %.1e" % (label, f, e, TOL_SIZE)
+    for f in ENV_FIELDS:
+        e = rel_err(gb[f][alive], rb[f][alive])
+        report[f] = e
+        assert e <= TOL_TRAJ, "%s: env %s rel err %.3e" % (label, f, e)
+    for k in range(racc.shape[0]):
+        e = rel_err(gacc[k], racc[k])
+        report["acc%d" % k] = e
+        assert e <= TOL_GRID, "%s: accumulator plane %d rel err %.3e > %.1e" % (label, k, e, TOL_GRID)
+    for k in range(rout.shape[0]):
+        e = rel_err(gout[k], rout[k])
+        report["out%d" % k] = e
+        assert e <= TOL_GRID, "%s: output plane %d rel err %.3e > %.1e" % (label, k, e, TOL_GRID)
+    # scalars: counters exact, heat within summation-order tolerance
+    from icebergs_amd import types as T
+    for name in ("nbergs_melted", "nbergs_calved_fl", "nspeeding_tickets", "nbergs_alive", "error_count"):
+        k = T.SCALAR_NAMES[name]
+        assert rscal[k] == gscal[k], "%s: scalar %s %r != %r" % (label, name, gscal[k], rscal[k])
+    k = T.SCALAR_NAMES["net_heat_to_ocean"]
+    assert abs(gscal[k] - rscal[k]) <= 1e-9 * max(abs(rscal[k]), 1e-300) + 0.0 or rscal[k] == gscal[k]
+    return report

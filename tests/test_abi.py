@@ -1,0 +1,57 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/kid.h declares, and agrees with
+the header about struct layouts.  No compute calls (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+from icebergs_amd import lib as L
+from icebergs_amd import types as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    L.build()
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "kid.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(kid_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match():
+    lib = L.load()
+    assert lib.kid_sizeof(0) == C.sizeof(T.Params)
+    assert lib.kid_sizeof(1) == C.sizeof(T.GridDesc)
+    assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
+    assert lib.kid_version().startswith(b"kid_hip")
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a device kid_create must fail (KID_ENODEV), never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from icebergs_amd import synthetic as S
+    from icebergs_amd.framework import Icebergs
+    grid, p, b = S.config_c1()
+    try:
+        Icebergs(grid, p, capacity=16)
+    except L.KidError as e:
+        assert "rc=-3" in str(e) or "rc=-2" in str(e)
+    else:
+        raise AssertionError("kid_create succeeded without a GPU")
+
+
+def test_product_never_touches_the_oracle():
+    """The product package must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "icebergs_amd")
+    banned = re.compile(r"oracle_lib|kid_oracle|libkid_oracle|oracle/|import\s+oracle|from\s+oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".F90", ".f90", ".c", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not banned.search(text), os.path.join(dirpath, f)

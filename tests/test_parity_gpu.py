@@ -1,0 +1,138 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (SURVEY.md 8d / BASELINE.json): trajectories and berg sizes 1e-10 relative, per-cell fields 1e-9
+relative to the field max; cell indices, the set of surviving bergs and event counters exact.
+"""
+import numpy as np
+import pytest
+
+from icebergs_amd import synthetic as S
+import parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(grid, p, b, nsteps, mode):
+    ref = P.run_oracle(grid, p, b, nsteps)
+    got = P.run_hip(grid, p, b, nsteps, mode=mode)
+    return ref, got
+
+
+@pytest.mark.parametrize("mode", ["fused", "phases"])
+def test_c1_rk4_defaults(oracle, mode):
+    """BASELINE config 1: 10 bergs, 20x20 f-plane Cartesian grid, RK4 + old_bug_bilin=T, 144 steps of 600 s."""
+    grid, p, b = S.config_c1()
+    S.set_diag_all(p)
+    ref, got = _both(grid, p, b, 144, mode)
+    rep = P.compare(ref, got, "C1/rk4/" + mode)
+    assert ref[0]["alive"].sum() >= 6  # most bergs stay on the 20x20 domain
+    print({k: v for k, v in rep.items() if k in ("lon", "lat", "uvel", "mass")})
+
+
+@pytest.mark.parametrize("mode", ["fused", "phases"])
+def test_c1_verlet_newbilin(oracle, mode):
+    """Config 1 run the second way SURVEY 8d asks for: Verlet + old_bug_bilin=F."""
+    grid, p, b = S.config_c1()
+    p.Runge_not_Verlet = 0
+    p.old_bug_bilin = 0
+    S.set_diag_all(p)
+    ref, got = _both(grid, p, b, 144, mode)
+    P.compare(ref, got, "C1/verlet/" + mode)
+
+
+def test_c1_verlet_new_interp_order(oracle):
+    """.not.old_interp_flds_order: environment interpolated once before evolve and once before thermodynamics
+    (IB:5423, 5473), as the footloose/MTS profiles run."""
+    grid, p, b = S.config_c1()
+    p.Runge_not_Verlet = 0
+    p.old_bug_bilin = 0
+    p.old_interp_flds_order = 0
+    p.use_new_predictive_corrective = 1
+    for mode in ("fused", "phases"):
+        ref, got = _both(grid, p, b, 60, mode)
+        P.compare(ref, got, "C1/verlet-neworder/" + mode)
+
+
+@pytest.mark.parametrize("continents", [False, True])
+def test_c2_latlon(oracle, continents):
+    """BASELINE config 2 at an oracle-sized population: lat-lon 360x200 (calc_xiyj path), RK4, melt,
+    rectangular mass spreading; `continents` adds land rectangles so that bergs bounce off coasts."""
+    grid, p, b = S.config_c2(n=40000, seed=2, continents=continents)
+    ref, got = _both(grid, p, b, 12, "fused")
+    P.compare(ref, got, "C2/continents=%s" % continents)
+
+
+def test_c2_phases_equals_fused(oracle):
+    grid, p, b = S.config_c2(n=20000, seed=7)
+    S.set_diag_all(p)
+    a = P.run_hip(grid, p, b, 5, mode="fused")
+    c = P.run_hip(grid, p, b, 5, mode="phases")
+    for f in P.TRAJ_FIELDS + P.SIZE_FIELDS:
+        assert np.array_equal(a[0][f], c[0][f]), f  # same device arithmetic -> bitwise equal state
+    for k in range(a[1].shape[0]):
+        assert P.rel_err(a[1][k], c[1][k]) <= 1e-12
+
+
+def test_c2_bergy_bits_and_rolling_schemes(oracle):
+    grid, p, b = S.config_c2(n=20000, seed=11)
+    p.bergy_bit_erosion_fraction = 0.4
+    p.use_updated_rolling_scheme = 1
+    p.use_old_spreading = 0
+    p.speed_limit = 0.05
+    S.set_diag_all(p)
+    ref, got = _both(grid, p, b, 8, "fused")
+    P.compare(ref, got, "C2/bergy-bits")
+    assert ref[3][1] >= 0  # counters compared exactly inside compare()
+
+
+def test_melting_to_death_and_compaction(oracle):
+    """Small warm-water bergs melt completely: deletion (IB:3271-3296) and SoA compaction."""
+    from icebergs_amd.framework import Icebergs
+    grid, p, b = S.config_c2(n=5000, seed=5)
+    grid["forcing"]["sst"][:] = 12.0
+    b["mass"] *= 1e-3
+    b["thickness"][:] = 8.0
+    b["width"] = np.sqrt(b["mass"] / (1.5 * 850.0 * b["thickness"]))
+    b["length"] = 1.5 * b["width"]
+    p.dt = 86400.0
+    ref = P.run_oracle(grid, p, b, 10)
+    got = P.run_hip(grid, p, b, 10, mode="fused")
+    P.compare(ref, got, "melt-to-death")
+    assert ref[3][1] > 0, "the test must actually melt some bergs"
+    ib = Icebergs(grid, p, capacity=len(b["lon"]))
+    ib.upload_bergs(b)
+    ib.run(10)
+    slots, alive = ib.num_bergs()
+    ib.compact()
+    slots2, alive2 = ib.num_bergs()
+    assert slots2 == alive == alive2 < slots
+    cb = ib.download_bergs()
+    keep = got[0]["alive"] != 0
+    assert np.array_equal(cb["id"], got[0]["id"][keep])
+    assert np.array_equal(cb["lon"], got[0]["lon"][keep])
+    ib.close()
+
+
+def test_empty_and_ragged_populations(oracle):
+    """Edge cases: a population that is not a multiple of the wave/block size, a single berg, no bergs."""
+    from icebergs_amd.framework import Icebergs
+    for n in (1, 63, 65, 257):
+        grid, p, b = S.config_c2(n=n, seed=100 + n)
+        ref, got = _both(grid, p, b, 3, "fused")
+        P.compare(ref, got, "ragged n=%d" % n)
+    grid, p, b = S.config_c2(n=1, seed=3)
+    ib = Icebergs(grid, p, capacity=8)
+    e = S.empty_bergs(0)
+    ib.upload_bergs(e)
+    ib.run(2)
+    acc, out, scal = ib.fetch()
+    assert not acc.any() and not out.any()
+    ib.close()
+
+
+def test_hexagonal_spreading(oracle):
+    grid, p, b = S.config_c2(n=8000, seed=21)
+    p.hexagonal_icebergs = 1
+    p.initial_orientation = 10.0
+    ref, got = _both(grid, p, b, 3, "fused")
+    P.compare(ref, got, "hexagonal")

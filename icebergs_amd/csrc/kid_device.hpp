@@ -13,6 +13,10 @@
 
 namespace kid {
 
+// Keeps the machine scheduler from interleaving two long phases (each wants ~100 VGPRs for its own loads in
+// flight); without it the RK4 stage body needs ~300 registers and spills, with it the kernel fits 2-3 waves/SIMD.
+#define KID_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // reference module constants, IB:68-80
 constexpr double RHO_ICE = 916.7, RHO_AIR = 1.1, RHO_SEAWATER = 1025.0, GRAVITY = 9.8;
 constexpr double CD_AV = 1.3, CD_AH = 0.0055, CD_WV = 0.9, CD_WH = 0.0012, CD_IV = 0.9;
@@ -103,6 +107,7 @@ __device__ __forceinline__ bool cell_in_data_domain(const DevGrid &g, int i, int
   return !(i - 1 < g.isd || i > g.ied || j - 1 < g.jsd || j > g.jed);
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ bool is_point_in_cell(const DevGrid &g, const Corners &q, double x, double y) {  // FW:6102-6158
   const double Lx = g.Lx;
   const double a = mod_around(q.lon00, x, Lx), b = mod_around(q.lon10, x, Lx);
@@ -113,7 +118,7 @@ __device__ __forceinline__ bool is_point_in_cell(const DevGrid &g, const Corners
   const double ylo = dmin(dmin(dmin(q.lat00, q.lat10), q.lat01), q.lat11);
   const double yhi = dmax(dmax(dmax(q.lat00, q.lat10), q.lat01), q.lat11);
   if (y < ylo || y > yhi) return false;
-  if (g.latlon && yhi > 89.999) {  // one corner at the pole: five-sided polygon (cold path)
+  if (!FAST && g.latlon && yhi > 89.999) {  // one corner at the pole: five-sided polygon (cold path; FAST bails earlier)
     if (q.lat11 > 89.999)
       return sum_sign_dot_prod5(q.lon00, q.lat00, q.lon10, q.lat10, q.lon10, q.lat11, q.lon01, q.lat11, q.lon01, q.lat01, x, y, Lx);
     else if (q.lat01 > 89.999)
@@ -157,9 +162,32 @@ __device__ __forceinline__ bool calc_xiyj(double x1, double x2, double x3, doubl
   return ok;
 }
 
+// FW:6359-6404: a cell with a corner at the pole is searched on the co-latitude tangent plane
+__device__ __noinline__ void pos_within_polar_cell(const DevGrid &g, const kid_params &p, const Corners &q, double x, double y,
+                                                   double &xi, double &yj, int &err) {
+  const double pi_180 = p.pi / 180.;
+  const double xx = (90. - y) * cos(x * pi_180), yy = (90. - y) * sin(x * pi_180);
+  const double x1 = (90. - q.lat00) * cos(q.lon00 * pi_180), y1 = (90. - q.lat00) * sin(q.lon00 * pi_180);
+  const double x2 = (90. - q.lat10) * cos(q.lon10 * pi_180), y2 = (90. - q.lat10) * sin(q.lon10 * pi_180);
+  const double x3 = (90. - q.lat11) * cos(q.lon11 * pi_180), y3 = (90. - q.lat11) * sin(q.lon11 * pi_180);
+  const double x4 = (90. - q.lat01) * cos(q.lon01 * pi_180), y4 = (90. - q.lat01) * sin(q.lon01 * pi_180);
+  if (!calc_xiyj(x1, x2, x3, x4, y1, y2, y3, y4, xx, yy, xi, yj, g.Lx)) err = 1;
+  if (is_point_in_cell(g, q, x, y)) {
+    if (!((xi >= 0. && xi < 1.) && (yj >= 0. && yj < 1.))) {
+      double fac = 2.1 * dmax(fabs(xi - 0.5), fabs(yj - 0.5)); fac = dmax(1., fac);
+      xi = 0.5 + (xi - 0.5) / fac;
+      yj = 0.5 + (yj - 0.5) / fac;
+    }
+  } else if (fabs(xi - 0.5) < 0.5 && fabs(yj - 0.5) < 0.5) err = 1;
+}
+
 // FW:6299-6436 (debug=.false.).  err is set on the reference's FATAL paths.
+// FAST: the specialised hot-path build.  Anything rare (polar cells, a berg leaving its cell, the polar tangent
+// plane) sets `bail` instead of being handled; the kernel then leaves that berg untouched and queues it for the
+// general (FAST=false) build of the same code, which runs on the short list of such bergs.
+template <bool FAST>
 __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_params &p, double x, double y, int i, int j,
-                                                double &xi, double &yj, int &err) {
+                                                double &xi, double &yj, int &err, bool &bail) {
   xi = -999.; yj = -999.;
   if (!cell_in_data_domain(g, i, j)) return false;
   const Corners q = load_corners(g, i, j);
@@ -171,23 +199,11 @@ __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_para
     yj = ((y - y1) / ddy) + 0.5;
   } else if (!g.latlon || dmax(dmax(dmax(q.lat00, q.lat10), q.lat11), q.lat01) < 89.999) {
     if (!calc_xiyj(q.lon00, q.lon10, q.lon11, q.lon01, q.lat00, q.lat10, q.lat11, q.lat01, x, y, xi, yj, g.Lx)) err = 1;
-  } else {  // polar cell: co-latitude tangent plane (FW:6359-6404), cold
-    const double pi_180 = p.pi / 180.;
-    const double xx = (90. - y) * cos(x * pi_180), yy = (90. - y) * sin(x * pi_180);
-    const double x1 = (90. - q.lat00) * cos(q.lon00 * pi_180), y1 = (90. - q.lat00) * sin(q.lon00 * pi_180);
-    const double x2 = (90. - q.lat10) * cos(q.lon10 * pi_180), y2 = (90. - q.lat10) * sin(q.lon10 * pi_180);
-    const double x3 = (90. - q.lat11) * cos(q.lon11 * pi_180), y3 = (90. - q.lat11) * sin(q.lon11 * pi_180);
-    const double x4 = (90. - q.lat01) * cos(q.lon01 * pi_180), y4 = (90. - q.lat01) * sin(q.lon01 * pi_180);
-    if (!calc_xiyj(x1, x2, x3, x4, y1, y2, y3, y4, xx, yy, xi, yj, g.Lx)) err = 1;
-    if (is_point_in_cell(g, q, x, y)) {
-      if (!((xi >= 0. && xi < 1.) && (yj >= 0. && yj < 1.))) {
-        double fac = 2.1 * dmax(fabs(xi - 0.5), fabs(yj - 0.5)); fac = dmax(1., fac);
-        xi = 0.5 + (xi - 0.5) / fac;
-        yj = 0.5 + (yj - 0.5) / fac;
-      }
-    } else if (fabs(xi - 0.5) < 0.5 && fabs(yj - 0.5) < 0.5) err = 1;
+  } else {  // polar cell: co-latitude tangent plane (FW:6359-6404), cold and out of line
+    if (FAST) { bail = true; return false; }
+    else pos_within_polar_cell(g, p, q, x, y, xi, yj, err);
   }
-  return is_point_in_cell(g, q, x, y);
+  return is_point_in_cell<FAST>(g, q, x, y);
 }
 
 // FW:7071-7088 on the corner coordinates (used when a berg bounces, IB:7990-7991, 8050-8051)
@@ -359,14 +375,12 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
 // ---------------------------------------------------------------------------------------------------------
 // IB:7819-8063 adjust_index_and_ground (debug=.false.)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, double &lon, double &lat,
-                                                        int &i, int &j, double &xi, double &yj, int &err) {
+__device__ __noinline__ void adjust_index_slow(const DevGrid &g, const kid_params &p, double &lon, double &lat,
+                                              int &i, int &j, double &xi, double &yj, int &err) {
+  // cold path: hop cells / bounce off land.  (The second pos_within_cell(i0,j0) of IB:7940 repeats the caller's.)
   constexpr double posn_eps = 0.05;
-  bool lret = pos_within_cell(g, p, lon, lat, i, j, xi, yj, err);
-  if (lret) return;  // the common case: still in its cell
-  // cold path: hop cells / bounce off land.  (The second pos_within_cell(i0,j0) of IB:7940 repeats the call above.)
   const int i0 = i, j0 = j;
-  bool bounced = false;
+  bool bounced = false, lret = false, unused_bail = false;
   for (int icount = 0; !lret && icount < 4; ++icount) {
     if (xi < 0.) {
       if (i > g.isd) { if (g.geo[g.idx(i - 1, j)].msk > 0.) { if (i > g.isd + 1) i = i - 1; } else bounced = true; }
@@ -385,7 +399,7 @@ __device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const 
       if (yj < 0.) yj = posn_eps;
       bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
     }
-    lret = pos_within_cell(g, p, lon, lat, i, j, xi, yj, err);
+    lret = pos_within_cell<false>(g, p, lon, lat, i, j, xi, yj, err, unused_bail);
   }
   if (!bounced && lret && g.geo[g.idx(i, j)].msk > 0.) return;
   if (!bounced && !lret) {
@@ -399,7 +413,14 @@ __device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const 
   if (yj > 1.) yj = 1. - posn_eps;
   if (yj <= 0.) yj = posn_eps;
   bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
-  (void)pos_within_cell(g, p, lon, lat, i, j, xi, yj, err);
+  (void)pos_within_cell<false>(g, p, lon, lat, i, j, xi, yj, err, unused_bail);
+}
+template <bool FAST>
+__device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, double &lon, double &lat,
+                                                        int &i, int &j, double &xi, double &yj, int &err, bool &bail) {
+  if (pos_within_cell<FAST>(g, p, lon, lat, i, j, xi, yj, err, bail)) return;  // the common case: still in its cell
+  if (FAST) bail = true;
+  else adjust_index_slow(g, p, lon, lat, i, j, xi, yj, err);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -448,100 +469,88 @@ struct BergDyn {
 
 // ---------------------------------------------------------------------------------------------------------
 // IB:7331-7679 Runge_Kutta_stepping.  env is only read when .not.old_interp_flds_order.
+//
+// The four stages run as ONE loop body (not unrolled): the whole kernel has to stay inside the 64 KB
+// instruction cache a CU pair shares, and four inlined copies of interp_flds + accel + the cell search do not.
+// The reference's sums (u1+u4)+2(u2+u3) are kept bit-for-bit by carrying the two partial sums A=(x1[+x4]) and
+// B=(x2[+x3]) per quantity.  On the polar tangent plane (lat>89, IB:7393) the same loop advances the
+// tangent-plane position/velocity instead; its rot* helpers are out of line (cold).
 // ---------------------------------------------------------------------------------------------------------
-template <bool OLD_ORDER>
+template <bool OLD_ORDER, bool FAST>
 __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
-                                         BergDyn &d, unsigned &tickets, int &err) {
+                                         BergDyn &d, unsigned &tickets, int &err, bool &bail) {
   const double dt = p.dt, dt_2 = 0.5 * dt, dt_6 = dt / 6.;
   const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
   const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
   const int i1 = d.ine, j1 = d.jne;
   const double xi1 = d.xi, yj1 = d.yj, lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
-  const bool on_tang = (lat1 > 89.) && g.latlon;
+  const bool on_tang = FAST ? false : ((lat1 > 89.) && g.latlon);
+  if (FAST && (lat1 > 89.) && g.latlon) { bail = true; return; }
   Env e = stored;
   double bxn = 0., byn = 0.;
-  // stage 1
-  double x1 = 0, y1 = 0, xdot1 = 0, ydot1 = 0;
+  double x1 = 0., y1 = 0., xdot1 = 0., ydot1 = 0.;
   if (on_tang) { rotpos_to_tang(p, lon1, lat1, x1, y1); rotvec_to_tang(p, lon1, uvel1, vvel1, xdot1, ydot1); }
-  LatTerms lt = lat_terms(g, p, lat1, sin_ref);
-  const double u1 = uvel1 * lt.dxdl, v1 = vvel1 * dydl;
-  double ax1, ay1, axn1 = d.axn, ayn1 = d.ayn;
-  if (OLD_ORDER) interp_flds(g, p, i1, j1, xi1, yj1, e);
-  accel<true>(g, p, bg, e, i1, j1, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt_2, ax1, ay1, axn1, ayn1, bxn, byn, tickets);
-  double xddot1 = 0, yddot1 = 0, xddot1n = 0, yddot1n = 0;
-  if (on_tang) { rotvec_to_tang(p, lon1, ax1, ay1, xddot1, yddot1); rotvec_to_tang(p, lon1, axn1, ayn1, xddot1n, yddot1n); }
-  // stage 2
-  double lon2, lat2, uvel2, vvel2, xdot2 = 0, ydot2 = 0;
-  if (on_tang) {
-    const double x2 = x1 + dt_2 * xdot1, y2 = y1 + dt_2 * ydot1;
-    xdot2 = xdot1 + dt_2 * xddot1; ydot2 = ydot1 + dt_2 * yddot1;
-    rotpos_from_tang(p, x2, y2, lon2, lat2); rotvec_from_tang(p, lon2, xdot2, ydot2, uvel2, vvel2);
-  } else { lon2 = lon1 + dt_2 * u1; lat2 = lat1 + dt_2 * v1; uvel2 = uvel1 + dt_2 * ax1; vvel2 = vvel1 + dt_2 * ay1; }
+  // partial sums: A = q1 (+ q4), B = q2 (+ q3) for q in {u, v, ax, ay, axn, ayn} (or their tangent-plane twins)
+  double Au = 0., Bu = 0., Av = 0., Bv = 0., Aax = 0., Bax = 0., Aay = 0., Bay = 0., Aaxn = 0., Baxn = 0., Aayn = 0., Bayn = 0.;
+  double lon_s = lon1, lat_s = lat1, uvel_s = uvel1, vvel_s = vvel1, xdot_s = xdot1, ydot_s = ydot1;
   int i = i1, j = j1; double xi = xi1, yj = yj1;
-  adjust_index_and_ground(g, p, lon2, lat2, i, j, xi, yj, err);
-  lt = lat_terms(g, p, lat2, sin_ref);
-  const double u2 = uvel2 * lt.dxdl, v2 = vvel2 * dydl;
-  double ax2, ay2, axn2 = d.axn, ayn2 = d.ayn;
-  if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
-  accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel2, vvel2, uvel1, vvel1, dt_2, ax2, ay2, axn2, ayn2, bxn, byn, tickets);
-  double xddot2 = 0, yddot2 = 0, xddot2n = 0, yddot2n = 0;
-  if (on_tang) { rotvec_to_tang(p, lon2, ax2, ay2, xddot2, yddot2); rotvec_to_tang(p, lon2, axn2, ayn2, xddot2n, yddot2n); }
-  // stage 3
-  double lon3, lat3, uvel3, vvel3, xdot3 = 0, ydot3 = 0;
-  if (on_tang) {
-    const double x3 = x1 + dt_2 * xdot2, y3 = y1 + dt_2 * ydot2;
-    xdot3 = xdot1 + dt_2 * xddot2; ydot3 = ydot1 + dt_2 * yddot2;
-    rotpos_from_tang(p, x3, y3, lon3, lat3); rotvec_from_tang(p, lon3, xdot3, ydot3, uvel3, vvel3);
-  } else { lon3 = lon1 + dt_2 * u2; lat3 = lat1 + dt_2 * v2; uvel3 = uvel1 + dt_2 * ax2; vvel3 = vvel1 + dt_2 * ay2; }
-  i = i1; j = j1; xi = xi1; yj = yj1;
-  adjust_index_and_ground(g, p, lon3, lat3, i, j, xi, yj, err);
-  lt = lat_terms(g, p, lat3, sin_ref);
-  const double u3 = uvel3 * lt.dxdl, v3 = vvel3 * dydl;
-  double ax3, ay3, axn3 = d.axn, ayn3 = d.ayn;
-  if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
-  accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel3, vvel3, uvel1, vvel1, dt, ax3, ay3, axn3, ayn3, bxn, byn, tickets);
-  double xddot3 = 0, yddot3 = 0, xddot3n = 0, yddot3n = 0;
-  if (on_tang) { rotvec_to_tang(p, lon3, ax3, ay3, xddot3, yddot3); rotvec_to_tang(p, lon3, axn3, ayn3, xddot3n, yddot3n); }
-  // stage 4
-  double lon4, lat4, uvel4, vvel4, xdot4 = 0, ydot4 = 0;
-  if (on_tang) {
-    const double x4 = x1 + dt * xdot3, y4 = y1 + dt * ydot3;
-    xdot4 = xdot1 + dt * xddot3; ydot4 = ydot1 + dt * yddot3;
-    rotpos_from_tang(p, x4, y4, lon4, lat4); rotvec_from_tang(p, lon4, xdot4, ydot4, uvel4, vvel4);
-  } else { lon4 = lon1 + dt * u3; lat4 = lat1 + dt * v3; uvel4 = uvel1 + dt * ax3; vvel4 = vvel1 + dt * ay3; }
-  i = i1; j = j1; xi = xi1; yj = yj1;
-  adjust_index_and_ground(g, p, lon4, lat4, i, j, xi, yj, err);
-  lt = lat_terms(g, p, lat4, sin_ref);
-  const double u4 = uvel4 * lt.dxdl, v4 = vvel4 * dydl;
-  double ax4, ay4, axn4 = d.axn, ayn4 = d.ayn;
-  if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
-  accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel4, vvel4, uvel1, vvel1, dt, ax4, ay4, axn4, ayn4, bxn, byn, tickets);
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST>(g, p, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
+    KID_PHASE_FENCE();
+    const LatTerms lt = lat_terms(g, p, lat_s, sin_ref);
+    double qu = uvel_s * lt.dxdl, qv = vvel_s * dydl;          // u_k, v_k  IB:7412
+    KID_PHASE_FENCE();
+    double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
+    if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
+    KID_PHASE_FENCE();
+    accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel_s, vvel_s, uvel1, vvel1, (s < 2) ? dt_2 : dt, ax, ay, axn_s, ayn_s, bxn, byn, tickets);
+    KID_PHASE_FENCE();
+    double qax = ax, qay = ay, qaxn = axn_s, qayn = ayn_s;
+    if (on_tang) {
+      qu = xdot_s; qv = ydot_s;
+      rotvec_to_tang(p, lon_s, ax, ay, qax, qay);
+      rotvec_to_tang(p, lon_s, axn_s, ayn_s, qaxn, qayn);
+    }
+    if (s == 0)      { Au = qu; Av = qv; Aax = qax; Aay = qay; Aaxn = qaxn; Aayn = qayn; }
+    else if (s == 1) { Bu = qu; Bv = qv; Bax = qax; Bay = qay; Baxn = qaxn; Bayn = qayn; }
+    else if (s == 2) { Bu = Bu + qu; Bv = Bv + qv; Bax = Bax + qax; Bay = Bay + qay; Baxn = Baxn + qaxn; Bayn = Bayn + qayn; }
+    else             { Au = Au + qu; Av = Av + qv; Aax = Aax + qax; Aay = Aay + qay; Aaxn = Aaxn + qaxn; Aayn = Aayn + qayn; }
+    if (s < 3) {  // X_{k+1} = X1 + c V_k ; V_{k+1} = V1 + c A_k   (c = dt/2, dt/2, dt)
+      const double c = (s < 2) ? dt_2 : dt;
+      if (on_tang) {
+        const double xs = x1 + c * qu, ys = y1 + c * qv;
+        xdot_s = xdot1 + c * qax; ydot_s = ydot1 + c * qay;
+        rotpos_from_tang(p, xs, ys, lon_s, lat_s);
+        rotvec_from_tang(p, lon_s, xdot_s, ydot_s, uvel_s, vvel_s);
+      } else {
+        lon_s = lon1 + c * qu; lat_s = lat1 + c * qv;
+        uvel_s = uvel1 + c * ax; vvel_s = vvel1 + c * ay;
+      }
+    }
+  }
   // combine IB:7597-7616
   double lonn, latn, uveln, vveln, axn, ayn;
   if (on_tang) {
-    double xddot4, yddot4, xddot4n, yddot4n;
-    rotvec_to_tang(p, lon4, ax4, ay4, xddot4, yddot4); rotvec_to_tang(p, lon4, axn4, ayn4, xddot4n, yddot4n);
-    const double xn = x1 + dt_6 * ((xdot1 + xdot4) + 2. * (xdot2 + xdot3));
-    const double yn = y1 + dt_6 * ((ydot1 + ydot4) + 2. * (ydot2 + ydot3));
-    const double xdotn = xdot1 + dt_6 * ((xddot1 + xddot4) + 2. * (xddot2 + xddot3));
-    const double ydotn = ydot1 + dt_6 * ((yddot1 + yddot4) + 2. * (yddot2 + yddot3));
-    const double xddotn = ((xddot1n + xddot4n) + 2. * (xddot2n + xddot3n)) / 6.;
-    const double yddotn = ((yddot1n + yddot4n) + 2. * (yddot2n + yddot3n)) / 6.;
+    const double xn = x1 + dt_6 * (Au + 2. * Bu), yn = y1 + dt_6 * (Av + 2. * Bv);
+    const double xdotn = xdot1 + dt_6 * (Aax + 2. * Bax), ydotn = ydot1 + dt_6 * (Aay + 2. * Bay);
+    const double xddotn = (Aaxn + 2. * Baxn) / 6., yddotn = (Aayn + 2. * Bayn) / 6.;
     rotpos_from_tang(p, xn, yn, lonn, latn);
     rotvec_from_tang(p, lonn, xdotn, ydotn, uveln, vveln);
     rotvec_from_tang(p, lonn, xddotn, yddotn, axn, ayn);  // bxn,byn stay as the 4th accel left them
   } else {
-    lonn = lon1 + dt_6 * ((u1 + u4) + 2. * (u2 + u3));
-    latn = lat1 + dt_6 * ((v1 + v4) + 2. * (v2 + v3));
-    uveln = uvel1 + dt_6 * ((ax1 + ax4) + 2. * (ax2 + ax3));
-    vveln = vvel1 + dt_6 * ((ay1 + ay4) + 2. * (ay2 + ay3));
-    axn = ((axn1 + axn4) + 2. * (axn2 + axn3)) / 6.;
-    ayn = ((ayn1 + ayn4) + 2. * (ayn2 + ayn3)) / 6.;
-    bxn = (((ax1 + ax4) + 2. * (ax2 + ax3)) / 6) - (axn / 2);
-    byn = (((ay1 + ay4) + 2. * (ay2 + ay3)) / 6) - (ayn / 2);
+    lonn = lon1 + dt_6 * (Au + 2. * Bu);
+    latn = lat1 + dt_6 * (Av + 2. * Bv);
+    uveln = uvel1 + dt_6 * (Aax + 2. * Bax);
+    vveln = vvel1 + dt_6 * (Aay + 2. * Bay);
+    axn = (Aaxn + 2. * Baxn) / 6.;
+    ayn = (Aayn + 2. * Bayn) / 6.;
+    bxn = ((Aax + 2. * Bax) / 6) - (axn / 2);
+    byn = ((Aay + 2. * Bay) / 6) - (ayn / 2);
   }
   i = i1; j = j1; xi = xi1; yj = yj1;
-  adjust_index_and_ground(g, p, lonn, latn, i, j, xi, yj, err);
+  KID_PHASE_FENCE();
+  adjust_index_and_ground<FAST>(g, p, lonn, latn, i, j, xi, yj, err, bail);
   if (p.override_iceberg_velocities) { uveln = p.u_override; vveln = p.v_override; }  // IB:7151-7154
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
   d.xi = xi; d.yj = yj; d.ine = i; d.jne = j;
@@ -550,9 +559,9 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
 // ---------------------------------------------------------------------------------------------------------
 // IB:7203-7328 verlet_stepping + IB:7684-7764 update_verlet_position (non-interactive)
 // ---------------------------------------------------------------------------------------------------------
-template <bool OLD_ORDER>
+template <bool OLD_ORDER, bool FAST>
 __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
-                                            BergDyn &d, unsigned &tickets, int &err) {
+                                            BergDyn &d, unsigned &tickets, int &err, bool &bail) {
   const double dt = p.dt, dt_2 = 0.5 * dt;
   const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
   const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
@@ -563,9 +572,11 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
   const LatTerms lt = lat_terms(g, p, lat1, sin_ref);
   Env e = stored;
   if (OLD_ORDER) interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e);
+  KID_PHASE_FENCE();
   double ax1, ay1, uveln, vveln;
   accel<false>(g, p, bg, e, d.ine, d.jne, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt, ax1, ay1, axn, ayn, bxn, byn, tickets);
-  const bool on_tang = (lat1 > 89.) && g.latlon;
+  const bool on_tang = FAST ? false : ((lat1 > 89.) && g.latlon);
+  if (FAST && (lat1 > 89.) && g.latlon) { bail = true; return; }
   if (on_tang) {
     double xdot3, ydot3, xddot1, yddot1;
     rotvec_to_tang(p, lon1, uvel3, vvel3, xdot3, ydot3);
@@ -585,7 +596,8 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
     const double u2 = uvel2 * lt.dxdl, v2 = vvel2 * dydl;
     lonn = lon1 + (dt * u2); latn = lat1 + (dt * v2);
   }
-  adjust_index_and_ground(g, p, lonn, latn, d.ine, d.jne, d.xi, d.yj, err);
+  KID_PHASE_FENCE();
+  adjust_index_and_ground<FAST>(g, p, lonn, latn, d.ine, d.jne, d.xi, d.yj, err, bail);
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
 }
 
@@ -611,7 +623,7 @@ __device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double 
     }
   }
 }
-__device__ __forceinline__ void fl_bits_dimensions(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
+__device__ __noinline__ void fl_bits_dimensions(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
   const double l_c = p.pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = 1. / (12. * (1. - pow(0.3, 2.)));
   const double l_w = pow(lw_c * p.fl_youngs * B_c * pow(thickness, 3.), 0.25);
   const double l_b = l_c * l_w;

@@ -81,14 +81,30 @@ __global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec
 // -------------------------------------------------------------------------------------------------------
 // the per-berg kernel
 // -------------------------------------------------------------------------------------------------------
-template <bool RK, bool OLD_ORDER, unsigned PH>
-__global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_params p, const BergPtrs b, const long long n,
-                                                   double *__restrict__ acc, const size_t ncell, const Flags fl) {
-  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
-  const bool inrange = k < n;
+#ifndef KID_WAVES_PER_EU
+#define KID_WAVES_PER_EU 2
+#endif
+// Two builds of the same body share the work of one phase:
+//   FAST=true  : every berg, specialised for the overwhelmingly common case (stays in its cell, not at the pole).
+//                A berg that meets anything else is left untouched and its index is appended to `redo`.
+//   FAST=false : the general code (cell hops, coast bounce, polar cells, tangent plane) over the `redo` list.
+// Keeping the rare branches out of the hot build roughly halves its register footprint (2 waves/SIMD, no scratch).
+struct Redo { int *list; int *count; };
+template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST>
+__global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(const DevGrid g, const kid_params p, const BergPtrs b, const long long n,
+                                                   double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
+  constexpr bool SCATTER = (PH & (PH_THERMO | PH_SPREAD)) != 0;
+  __shared__ double lds_vals[SCATTER ? KID_SEG_LDS_DOUBLES : 1];
+  __shared__ int lds_ints[SCATTER ? KID_SEG_LDS_INTS : 1];
+  // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
+  const long long total = FAST ? n : (long long)(*redo.count);
+  for (long long tid = (long long)blockIdx.x * 256ll + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * 256ll + threadIdx.x) : (tid - threadIdx.x < total));
+       tid += (long long)gridDim.x * 256ll) {
+  const bool inrange = tid < total;
+  const long long k = inrange ? (FAST ? tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
   const bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
-  if (__ballot(was_alive) == 0ull) return;  // wave-uniform
+  if (__ballot(was_alive) == 0ull) continue;  // wave-uniform; every other lane stays to the end (wave-level sums below)
   double *scal = acc + (size_t)KID_NACC * ncell;
 
   BergDyn d;
@@ -107,6 +123,8 @@ __global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_pa
   unsigned tickets = 0u;
   int err = 0;
   bool env_dirty = false;
+  bool bail = false;     // FAST build: this berg needs the general build
+  bool skipped = false;  // ... and has been queued: nothing of it may be written or accumulated here
 
   if ((PH & PH_INTERP) || (!OLD_ORDER && (PH & (PH_EVOLVE | PH_THERMO)))) {
     if (PH & PH_INTERP) {  // IB:4673-4715
@@ -124,16 +142,22 @@ __global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_pa
     const bool moves = was_alive && (t.static_berg < 0.5);
     if (moves) {
       const BergGeom bg{t.M, t.T, t.W, t.L, t.n_bonds};
-      if (RK) rk4_step<OLD_ORDER>(g, p, bg, e, d, tickets, err);
-      else verlet_step<OLD_ORDER>(g, p, bg, e, d, tickets, err);
-      // a berg whose cell leaves the computational domain is packed-and-deleted by send_bergs_to_other_pes on a
-      // PE without that neighbour (FW:3024-3041)
-      if (d.ine < g.isc || d.ine > g.iec || d.jne < g.jsc || d.jne > g.jec) t.alive = false;
-      b.f[KID_B_LON][kk] = d.lon; b.f[KID_B_LAT][kk] = d.lat; b.f[KID_B_UVEL][kk] = d.uvel; b.f[KID_B_VVEL][kk] = d.vvel;
-      b.f[KID_B_AXN][kk] = d.axn; b.f[KID_B_AYN][kk] = d.ayn; b.f[KID_B_BXN][kk] = d.bxn; b.f[KID_B_BYN][kk] = d.byn;
-      b.f[KID_B_XI][kk] = d.xi; b.f[KID_B_YJ][kk] = d.yj;
-      b.i[KID_BI_INE][kk] = d.ine; b.i[KID_BI_JNE][kk] = d.jne;
-      if (!RK) { b.f[KID_B_UVEL_PREV][kk] = d.uvel_prev; b.f[KID_B_VVEL_PREV][kk] = d.vvel_prev; }
+      if (RK) rk4_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail);
+      else verlet_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail);
+      if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
+        const int slot = atomicAdd(redo.count, 1);
+        redo.list[slot] = (int)kk;
+        skipped = true; tickets = 0u; err = 0;
+      } else {
+        // a berg whose cell leaves the computational domain is packed-and-deleted by send_bergs_to_other_pes on a
+        // PE without that neighbour (FW:3024-3041)
+        if (d.ine < g.isc || d.ine > g.iec || d.jne < g.jsc || d.jne > g.jec) t.alive = false;
+        b.f[KID_B_LON][kk] = d.lon; b.f[KID_B_LAT][kk] = d.lat; b.f[KID_B_UVEL][kk] = d.uvel; b.f[KID_B_VVEL][kk] = d.vvel;
+        b.f[KID_B_AXN][kk] = d.axn; b.f[KID_B_AYN][kk] = d.ayn; b.f[KID_B_BXN][kk] = d.bxn; b.f[KID_B_BYN][kk] = d.byn;
+        b.f[KID_B_XI][kk] = d.xi; b.f[KID_B_YJ][kk] = d.yj;
+        b.i[KID_BI_INE][kk] = d.ine; b.i[KID_BI_JNE][kk] = d.jne;
+        if (!RK) { b.f[KID_B_UVEL_PREV][kk] = d.uvel_prev; b.f[KID_B_VVEL_PREV][kk] = d.vvel_prev; }
+      }
     }
     const unsigned long long bt = __ballot(tickets != 0u);
     if (bt) {  // rare
@@ -141,15 +165,14 @@ __global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_pa
       if (__lane_id() == 0) unsafeAtomicAdd(scal + KID_S_NSPEEDING_TICKETS, ts);
     }
   }
+  KID_PHASE_FENCE();
 
   if (PH & (PH_THERMO | PH_SPREAD)) {
-    const bool active = t.alive;
-    const Seg seg = make_seg(active ? g.idx(d.ine, d.jne) : (-1 - (int)__lane_id()));
-    if ((PH & PH_THERMO) || fl.has_fl) {
-      t.mass_scaling = b.f[KID_B_MASS_SCALING][kk];
-      t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk];
-      t.heat_density = b.f[KID_B_HEAT_DENSITY][kk];
-    } else { t.mass_scaling = b.f[KID_B_MASS_SCALING][kk]; t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk]; t.heat_density = 0.; }
+    const bool active = t.alive && !skipped;
+    Seg seg = make_runs(active ? g.idx(d.ine, d.jne) : (-1 - (int)__lane_id()), (lds_double *)lds_vals, (lds_int *)lds_ints);
+    t.mass_scaling = b.f[KID_B_MASS_SCALING][kk];
+    t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk];
+    t.heat_density = (PH & PH_THERMO) ? b.f[KID_B_HEAT_DENSITY][kk] : 0.;
     if (fl.has_fl) {
       t.mass_of_fl_bits = b.f[KID_B_MASS_OF_FL_BITS][kk]; t.mass_of_fl_bergy_bits = b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk];
       t.fl_k = b.f[KID_B_FL_K][kk];
@@ -162,6 +185,7 @@ __global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_pa
         if (active) { interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e); env_dirty = true; }
         if (PH & PH_INTERP) e.od = od_keep;
       }
+      KID_PHASE_FENCE();
       const BergThermo before = t;
       thermodynamics(g, p, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
       if (active) {
@@ -176,18 +200,18 @@ __global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_pa
           }
         }
       }
+      KID_PHASE_FENCE();
     }
     if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
-      const bool act2 = t.alive;
-      // bergs that just melted away leave their run: rebuild the run structure so that no run loses its tail lane
-      const Seg seg2 = (__ballot(act2 != active) != 0ull) ? make_seg(act2 ? g.idx(d.ine, d.jne) : (-1 - (int)__lane_id())) : seg;
+      const bool act2 = t.alive && !skipped;
       if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
-        spread_mass(g, p, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg2);
-      berg_diagnostics(g, p, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg2);
+        spread_mass(g, p, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg);
+      berg_diagnostics(g, p, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
+    seg_flush(seg, acc, ncell);
   }
 
-  if (was_alive) {
+  if (was_alive && !skipped) {
     if (!t.alive) b.i[KID_BI_ALIVE][kk] = 0;
     if (env_dirty && fl.store_env) {
       b.f[KID_B_UO][kk] = e.uo; b.f[KID_B_VO][kk] = e.vo; b.f[KID_B_UI][kk] = e.ui; b.f[KID_B_VI][kk] = e.vi;
@@ -198,14 +222,16 @@ __global__ void __launch_bounds__(256) berg_kernel(const DevGrid g, const kid_pa
   }
   const unsigned long long be = __ballot(err != 0);
   if (be && __lane_id() == 0) unsafeAtomicAdd(scal + KID_S_ERROR_COUNT, (double)__popcll(be));
+  }  // grid-stride loop
 }
 
 // -------------------------------------------------------------------------------------------------------
 // IB:6077-6150 sum_up_spread_fields + IB:3449-3488, per cell of the computational domain
 // -------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_params p, double *__restrict__ acc,
-                                                     double *__restrict__ out, const size_t ncell) {
+                                                     double *__restrict__ out, const size_t ncell, double *__restrict__ totals) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < KID_NSCALAR) totals[t] += acc[(size_t)KID_NACC * ncell + t];  // running totals kept on `bergs` (IB:3130, 3295)
   const int nic = g.iec - g.isc + 1, njc = g.jec - g.jsc + 1;
   if (t >= nic * njc) return;
   const int i = g.isc + t % nic, j = g.jsc + t / nic;
@@ -298,9 +324,11 @@ struct kid_handle {
   VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr;
   double *d_acc_own = nullptr, *d_acc = nullptr;  // KID_NACC*ncell + KID_NSCALAR
   double *d_out = nullptr;                        // KID_NOUT*ncell
+  double *d_totals = nullptr;                     // KID_NSCALAR running totals (the block's scalars are per-step)
   BergPtrs bp{};
   double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
   unsigned long long *d_count = nullptr;
+  int *d_redo_list = nullptr, *d_redo_count = nullptr;  // bergs the FAST build hands to the general build
   Flags flags{0, 0, 1, 0};
   bool have_static = false, have_forcing = false;
   bool profile = false;
@@ -388,11 +416,15 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   h->d_acc = h->d_acc_own;
   KID_HIP(h, hipMalloc(&h->d_out, (size_t)KID_NOUT * h->ncell * sizeof(double)));
   KID_HIP(h, hipMemset(h->d_out, 0, (size_t)KID_NOUT * h->ncell * sizeof(double)));
+  KID_HIP(h, hipMalloc(&h->d_totals, KID_NSCALAR * sizeof(double)));
+  KID_HIP(h, hipMemset(h->d_totals, 0, KID_NSCALAR * sizeof(double)));
   for (int f = 0; f < KID_NB_F64; ++f) { KID_HIP(h, hipMalloc(&h->bp.f[f], (size_t)capacity * sizeof(double))); KID_HIP(h, hipMemset(h->bp.f[f], 0, (size_t)capacity * sizeof(double))); }
   for (int f = 0; f < KID_NB_I32; ++f) { KID_HIP(h, hipMalloc(&h->bp.i[f], (size_t)capacity * sizeof(int32_t))); KID_HIP(h, hipMemset(h->bp.i[f], 0, (size_t)capacity * sizeof(int32_t))); }
   KID_HIP(h, hipMalloc(&h->bp.id, (size_t)capacity * sizeof(int64_t)));
   KID_HIP(h, hipMemset(h->bp.id, 0, (size_t)capacity * sizeof(int64_t)));
   KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
+  KID_HIP(h, hipMalloc(&h->d_redo_list, (size_t)capacity * sizeof(int)));
+  KID_HIP(h, hipMalloc(&h->d_redo_count, sizeof(int)));
   KID_HIP(h, hipEventCreate(&h->ev0)); KID_HIP(h, hipEventCreate(&h->ev1));
   KID_HIP(h, hipEventCreate(&h->ev2)); KID_HIP(h, hipEventCreate(&h->ev3));
   return KID_OK;
@@ -409,6 +441,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_geo) (void)hipFree(h->d_geo);
   if (h->d_acc_own) (void)hipFree(h->d_acc_own);
   if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_totals) (void)hipFree(h->d_totals);
   for (auto &k : h->bp.f) if (k) (void)hipFree(k);
   for (auto &k : h->bp.i) if (k) (void)hipFree(k);
   if (h->bp.id) (void)hipFree(h->bp.id);
@@ -417,6 +450,8 @@ int kid_destroy(kid_handle *h) {
   if (h->d_flag) (void)hipFree(h->d_flag);
   if (h->d_scan_tmp) (void)hipFree(h->d_scan_tmp);
   if (h->d_count) (void)hipFree(h->d_count);
+  if (h->d_redo_list) (void)hipFree(h->d_redo_list);
+  if (h->d_redo_count) (void)hipFree(h->d_redo_count);
   for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -608,8 +643,8 @@ int kid_zero_accumulators(kid_handle *h) {
   KID_HIP(h, hipSetDevice(h->device));
   const size_t planes = (size_t)nacc_active(h);
   KID_HIP(h, hipMemsetAsync(h->d_acc, 0, planes * h->ncell * sizeof(double), h->stream));
-  // scalars other than the running totals are per-step; the reference keeps running totals on `bergs`
-  // (net_heat_to_ocean, nbergs_melted, ...): the caller reads increments, so zero them too.
+  // the KID_NSCALAR words behind the planes hold this step's increments of the running totals the reference
+  // keeps on `bergs` (net_heat_to_ocean, nbergs_melted, ...); the gather folds them into the totals.
   KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_NACC * h->ncell, 0, KID_NSCALAR * sizeof(double), h->stream));
   return KID_OK;
 }
@@ -628,7 +663,17 @@ static int launch_berg(kid_handle *h) {
     KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1));
     KID_HIP(h, hipEventRecord(e0, h->stream));
   }
-#define KID_LAUNCH(RKV, OLDV) hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH>), dim3(nb), dim3(256), 0, h->stream, g, h->params, h->bp, (long long)h->n, h->d_acc, h->ncell, h->flags)
+const Redo redo{h->d_redo_list, h->d_redo_count};
+  KID_HIP(h, hipMemsetAsync(h->d_redo_count, 0, sizeof(int), h->stream));
+  // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
+  // (a few per cent: cell crossings, coast bounces, polar cells).  Pass 2 is sized for the worst case and its
+  // surplus workgroups exit on the device-side count.
+#define KID_LAUNCH(RKV, OLDV)                                                                                                   \
+  do {                                                                                                                          \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nb), dim3(256), 0, h->stream, g, h->params, h->bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    if (PH & PH_EVOLVE)                                                                                                         \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nb < 512u ? nb : 512u), dim3(256), 0, h->stream, g, h->params, h->bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+  } while (0)
   if (rk && old) KID_LAUNCH(true, true);
   else if (rk && !old) KID_LAUNCH(true, false);
   else if (!rk && old) KID_LAUNCH(false, true);
@@ -665,8 +710,10 @@ int kid_footloose_calving(kid_handle *h) {
 static int launch_gather(kid_handle *h) {
   const DevGrid g = dev_grid(h);
   const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell);
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell, h->d_totals);
   KID_HIP(h, hipGetLastError());
+  // the step's increments are now folded into the totals
+  KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_NACC * h->ncell, 0, KID_NSCALAR * sizeof(double), h->stream));
   return KID_OK;
 }
 int kid_create_gridded_icebergs_fields(kid_handle *h) {
@@ -733,7 +780,7 @@ int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalar
   KID_HIP(h, hipSetDevice(h->device));
   if (acc) KID_HIP(h, hipMemcpyAsync(acc, h->d_acc, (size_t)KID_NACC * h->ncell * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (out) KID_HIP(h, hipMemcpyAsync(out, h->d_out, (size_t)KID_NOUT * h->ncell * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (scalars) KID_HIP(h, hipMemcpyAsync(scalars, h->d_acc + (size_t)KID_NACC * h->ncell, KID_NSCALAR * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (scalars) KID_HIP(h, hipMemcpyAsync(scalars, h->d_totals, KID_NSCALAR * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   KID_HIP(h, hipStreamSynchronize(h->stream));
   if (scalars) {
     int64_t alive = 0;

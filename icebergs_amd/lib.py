@@ -9,7 +9,7 @@ import subprocess
 from . import types as T
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SO_PATH = os.path.join(_CSRC, "libkid_hip.so")
+SO_PATH = os.environ.get("KID_HIP_SO", os.path.join(_CSRC, "libkid_hip.so"))  # override: A/B builds of experiments
 
 # every symbol include/kid.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [

@@ -83,7 +83,8 @@ int kid_step_gather(kid_handle *h);  /* 9-point gather + derived fields (after t
 int kid_run_step(kid_handle *h, int nsteps); /* nsteps x (kid_step_local; kid_step_gather) */
 
 /* ---- results ---- */
-/* acc: KID_NACC fields, out: KID_NOUT fields, each (ied-isd+1)*(jed-jsd+1); scalars: KID_NSCALAR. NULL skips. */
+/* acc: KID_NACC fields, out: KID_NOUT fields, each (ied-isd+1)*(jed-jsd+1); scalars: KID_NSCALAR running totals
+ * since kid_create (the reference keeps them on `bergs`). NULL skips. */
 int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalars);
 /* Device view of the accumulator block for RCCL: KID_NACC*ncell + KID_NSCALAR contiguous doubles. */
 int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count);

@@ -15,6 +15,11 @@ namespace kid {
 
 // Keeps the machine scheduler from interleaving two long phases (each wants ~100 VGPRs for its own loads in
 // flight); without it the RK4 stage body needs ~300 registers and spills, with it the kernel fits 2-3 waves/SIMD.
+#ifdef KID_EXP_MARKERS
+#define KID_MARK(name) asm volatile("; KIDMARK " name)
+#else
+#define KID_MARK(name) ((void)0)
+#endif
 #define KID_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // reference module constants, IB:68-80
@@ -40,6 +45,90 @@ struct DevGrid {
 };
 
 struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; };
+
+// ---------------------------------------------------------------------------------------------------------
+// Cell views: everything a berg reads from the grid around its cell (i,j).
+//   GlbCell reads the record arrays in global memory (general build).
+//   PkCell  reads a 68-double "cell packet" that the wave staged in LDS once per step (hot build): a berg of the
+//           hot build never leaves its cell (it bails out otherwise), so the four RK4 stages, the five cell
+//           searches and the thermodynamics interpolation all hit the same packet, and the cell-sorted lanes of a
+//           wave share a handful of packets.  This is the LDS staging of the forcing fields for the bilinear
+//           interpolation: ~270 per-lane global loads per berg-step become ~10 cooperative loads per wave.
+// Packet layout (doubles): corner records k = 0:(i-1,j-1) 1:(i,j-1) 2:(i-1,j) 3:(i,j)
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(3))) int lds_int;
+enum { PK_VEL = 0, PK_CORNER = 32, PK_T0 = 40, PK_DDX = 45, PK_DDY = 51, PK_AREA = 57, PK_MSK = 58, PK_SIZE = 67, PK_STRIDE = 68 };
+struct Corners { double lon00, lat00, lon10, lat10, lon11, lat11, lon01, lat01; };
+
+struct GlbCell {
+  const DevGrid &g;
+  int c;
+  __device__ __forceinline__ int corner_cell(int k) const { return c - ((k & 1) ? 0 : 1) - ((k & 2) ? 0 : g.ni); }
+  __device__ __forceinline__ double vel(int k, int f) const { return reinterpret_cast<const double *>(g.vel + corner_cell(k))[f]; }
+  __device__ __forceinline__ Corners corners() const {
+    const GeoRec a = g.geo[c - g.ni - 1], b = g.geo[c - g.ni], d = g.geo[c], e = g.geo[c - 1];
+    return Corners{a.lon, a.lat, b.lon, b.lat, d.lon, d.lat, e.lon, e.lat};
+  }
+  __device__ __forceinline__ double t0(int f) const { return reinterpret_cast<const double *>(g.trc + c)[f]; }
+  // ddx_ssh at (0,+1),(0,0),(0,-1),(-1,+1),(-1,0),(-1,-1); ddy_ssh at (+1,0),(0,0),(-1,0),(+1,-1),(0,-1),(-1,-1)
+  __device__ __forceinline__ double ddx(int k) const { return g.trc[c - (k / 3) + (1 - (k % 3)) * g.ni].ddx; }
+  __device__ __forceinline__ double ddy(int k) const { return g.trc[c + (1 - (k % 3)) - (k / 3) * g.ni].ddy; }
+  __device__ __forceinline__ double area() const { return g.geo[c].area; }
+  __device__ __forceinline__ double msk(int di, int dj) const { return g.geo[c + di + dj * g.ni].msk; }
+};
+struct PkCell {
+  const lds_double *pk;
+  __device__ __forceinline__ double vel(int k, int f) const { return pk[PK_VEL + k * 8 + f]; }
+  __device__ __forceinline__ Corners corners() const {
+    return Corners{pk[PK_CORNER + 0], pk[PK_CORNER + 1], pk[PK_CORNER + 2], pk[PK_CORNER + 3],
+                   pk[PK_CORNER + 6], pk[PK_CORNER + 7], pk[PK_CORNER + 4], pk[PK_CORNER + 5]};
+  }
+  __device__ __forceinline__ double t0(int f) const { return pk[PK_T0 + f]; }
+  __device__ __forceinline__ double ddx(int k) const { return pk[PK_DDX + k]; }
+  __device__ __forceinline__ double ddy(int k) const { return pk[PK_DDY + k]; }
+  __device__ __forceinline__ double area() const { return pk[PK_AREA]; }
+  __device__ __forceinline__ double msk(int di, int dj) const { return pk[PK_MSK + (di + 1) + 3 * (dj + 1)]; }
+};
+template <bool FAST> struct CellOf;
+template <> struct CellOf<true> {
+  typedef PkCell type;
+  static __device__ __forceinline__ PkCell make(const DevGrid &, const lds_double *pk, int, int) { return PkCell{pk}; }
+};
+template <> struct CellOf<false> {
+  typedef GlbCell type;
+  static __device__ __forceinline__ GlbCell make(const DevGrid &g, const lds_double *, int i, int j) { return GlbCell{g, g.idx(i, j)}; }
+};
+// One wave stages the packet of a cell into LDS: lane q fetches packet element q (and q+64).  Where element q
+// lives (which record array, which neighbour cell, which field) is fixed, so it is resolved once per lane:
+// address of element q for cell c = base + c * stride.
+struct PacketSrc { const char *base; long long stride; };
+__device__ __forceinline__ PacketSrc packet_source(const DevGrid &g, int q) {
+  const char *arr; long long stride, cell_off, field;
+  if (q < PK_CORNER) {            // 4 corner velocity records x 8 fields
+    const int k = q >> 3;
+    arr = reinterpret_cast<const char *>(g.vel); stride = sizeof(VelRec); field = q & 7;
+    cell_off = -((k & 1) ? 0 : 1) - ((k & 2) ? 0 : g.ni);
+  } else if (q < PK_T0) {         // corner lon/lat in the order 00,10,01,11
+    const int k = (q - PK_CORNER) >> 1;
+    arr = reinterpret_cast<const char *>(g.geo); stride = sizeof(GeoRec); field = (q - PK_CORNER) & 1;
+    cell_off = -((k & 1) ? 0 : 1) - ((k & 2) ? 0 : g.ni);
+  } else if (q < PK_DDX) {
+    arr = reinterpret_cast<const char *>(g.trc); stride = sizeof(TrcRec); field = q - PK_T0; cell_off = 0;
+  } else if (q < PK_DDY) {
+    const int k = q - PK_DDX;
+    arr = reinterpret_cast<const char *>(g.trc); stride = sizeof(TrcRec); field = 5; cell_off = -(k / 3) + (1 - (k % 3)) * g.ni;
+  } else if (q < PK_AREA) {
+    const int k = q - PK_DDY;
+    arr = reinterpret_cast<const char *>(g.trc); stride = sizeof(TrcRec); field = 6; cell_off = (1 - (k % 3)) - (k / 3) * g.ni;
+  } else if (q == PK_AREA) {
+    arr = reinterpret_cast<const char *>(g.geo); stride = sizeof(GeoRec); field = 2; cell_off = 0;
+  } else {
+    const int m = (q < PK_SIZE) ? q - PK_MSK : 4;
+    arr = reinterpret_cast<const char *>(g.geo); stride = sizeof(GeoRec); field = 3; cell_off = (m % 3 - 1) + (m / 3 - 1) * g.ni;
+  }
+  return PacketSrc{arr + cell_off * stride + field * 8, stride};
+}
 
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
@@ -96,13 +185,6 @@ __device__ __noinline__ bool sum_sign_dot_prod5(double x0, double y0, double x1,
   return (((fabs(p0) + fabs(p2)) + (fabs(p1) + fabs(p3))) + fabs(p4) - fabs(((p0 + p2) + (p1 + p3)) + p4)) < 0.5;
 }
 
-// the four corners of cell (i,j): 00=(i-1,j-1) 10=(i,j-1) 11=(i,j) 01=(i-1,j)
-struct Corners { double lon00, lat00, lon10, lat10, lon11, lat11, lon01, lat01; };
-__device__ __forceinline__ Corners load_corners(const DevGrid &g, int i, int j) {
-  const int c = g.idx(i, j);
-  const GeoRec a = g.geo[c - g.ni - 1], b = g.geo[c - g.ni], d = g.geo[c], e = g.geo[c - 1];
-  return Corners{a.lon, a.lat, b.lon, b.lat, d.lon, d.lat, e.lon, e.lat};
-}
 __device__ __forceinline__ bool cell_in_data_domain(const DevGrid &g, int i, int j) {
   return !(i - 1 < g.isd || i > g.ied || j - 1 < g.jsd || j > g.jed);
 }
@@ -185,12 +267,12 @@ __device__ __noinline__ void pos_within_polar_cell(const DevGrid &g, const kid_p
 // FAST: the specialised hot-path build.  Anything rare (polar cells, a berg leaving its cell, the polar tangent
 // plane) sets `bail` instead of being handled; the kernel then leaves that berg untouched and queues it for the
 // general (FAST=false) build of the same code, which runs on the short list of such bergs.
-template <bool FAST>
-__device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_params &p, double x, double y, int i, int j,
+template <bool FAST, class CELL>
+__device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_params &p, const CELL &cell, double x, double y, int i, int j,
                                                 double &xi, double &yj, int &err, bool &bail) {
   xi = -999.; yj = -999.;
   if (!cell_in_data_domain(g, i, j)) return false;
-  const Corners q = load_corners(g, i, j);
+  const Corners q = cell.corners();
   if (!g.latlon && g.regular) {
     const double ddx = fabs(q.lon11 - q.lon01), ddy = fabs(q.lat11 - q.lat10);
     const double x1 = q.lon11 - (ddx / 2), y1 = q.lat11 - (ddy / 2);
@@ -209,7 +291,7 @@ __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_para
 // FW:7071-7088 on the corner coordinates (used when a berg bounces, IB:7990-7991, 8050-8051)
 __device__ __forceinline__ void bilin_lonlat(const DevGrid &g, const kid_params &p, int i, int j, double xi, double yj,
                                              double &lon, double &lat) {
-  const Corners q = load_corners(g, i, j);
+  const Corners q = GlbCell{g, g.idx(i, j)}.corners();
   if (p.old_bug_bilin) {
     lon = (q.lon11 * (1. - xi) + q.lon01 * xi) * (1. - yj) + (q.lon10 * (1. - xi) + q.lon00 * xi) * yj;
     lat = (q.lat11 * (1. - xi) + q.lat01 * xi) * (1. - yj) + (q.lat10 * (1. - xi) + q.lat00 * xi) * yj;
@@ -222,42 +304,38 @@ __device__ __forceinline__ void bilin_lonlat(const DevGrid &g, const kid_params 
 // ---------------------------------------------------------------------------------------------------------
 // IB:4718-4900 interp_flds (non-MTS; tidal_drift = 0)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void interp_flds(const DevGrid &g, const kid_params &p, int i, int j, double xi, double yj, Env &e) {
-  const int c = g.idx(i, j);
-  const VelRec v11 = g.vel[c], v01 = g.vel[c - 1], v10 = g.vel[c - g.ni], v00 = g.vel[c - g.ni - 1];
+template <class CELL>
+__device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cell, double xi, double yj, Env &e) {
   double wx1, wx0, wy1, wy0;  // weights of columns i / i-1 and rows j / j-1 (FW:7081-7087)
   if (p.old_bug_bilin) { wx1 = 1. - xi; wx0 = xi; wy1 = 1. - yj; wy0 = yj; }
   else { wx1 = xi; wx0 = 1. - xi; wy1 = yj; wy0 = 1. - yj; }
-#define KID_BIL(f) ((v11.f * wx1 + v01.f * wx0) * wy1 + (v10.f * wx1 + v00.f * wx0) * wy0)
-  const double cos_rot = KID_BIL(cosr), sin_rot = KID_BIL(sinr);
-  double uo = KID_BIL(uo), vo = KID_BIL(vo), ui = KID_BIL(ui), vi = KID_BIL(vi), ua = KID_BIL(ua), va = KID_BIL(va);
+#define KID_BIL(f) ((cell.vel(3, f) * wx1 + cell.vel(2, f) * wx0) * wy1 + (cell.vel(1, f) * wx1 + cell.vel(0, f) * wx0) * wy0)
+  const double cos_rot = KID_BIL(0), sin_rot = KID_BIL(1);
+  double uo = KID_BIL(2), vo = KID_BIL(3), ui = KID_BIL(4), vi = KID_BIL(5), ua = KID_BIL(6), va = KID_BIL(7);
 #undef KID_BIL
-  const TrcRec t0 = g.trc[c];
   if (p.coastal_drift > 0.) {  // IB:4769-4776
-    const double mE = g.trc[c + 1].msk, mW = g.trc[c - 1].msk, mN = g.trc[c + g.ni].msk, mS = g.trc[c - g.ni].msk;
-    uo = uo + p.coastal_drift * (mE - mW) * t0.msk;
-    ui = ui + p.coastal_drift * (mE - mW) * t0.msk;
-    vo = vo + p.coastal_drift * (mN - mS) * t0.msk;
-    vi = vi + p.coastal_drift * (mN - mS) * t0.msk;
+    const double mE = cell.msk(1, 0), mW = cell.msk(-1, 0), mN = cell.msk(0, 1), mS = cell.msk(0, -1), m0 = cell.msk(0, 0);
+    uo = uo + p.coastal_drift * (mE - mW) * m0;
+    ui = ui + p.coastal_drift * (mE - mW) * m0;
+    vo = vo + p.coastal_drift * (mN - mS) * m0;
+    vi = vi + p.coastal_drift * (mN - mS) * m0;
   }
   // sea-surface slope from the hoisted per-cell stencils (IB:4830-4860)
   double hxp, hxm;
-  const double ddx_00 = t0.ddx, ddx_m0 = g.trc[c - 1].ddx;
   if (yj >= 0.5) {
-    hxp = (yj - 0.5) * g.trc[c + g.ni].ddx + (1.5 - yj) * ddx_00;
-    hxm = (yj - 0.5) * g.trc[c + g.ni - 1].ddx + (1.5 - yj) * ddx_m0;
+    hxp = (yj - 0.5) * cell.ddx(0) + (1.5 - yj) * cell.ddx(1);
+    hxm = (yj - 0.5) * cell.ddx(3) + (1.5 - yj) * cell.ddx(4);
   } else {
-    hxp = (yj + 0.5) * ddx_00 + (0.5 - yj) * g.trc[c - g.ni].ddx;
-    hxm = (yj + 0.5) * ddx_m0 + (0.5 - yj) * g.trc[c - g.ni - 1].ddx;
+    hxp = (yj + 0.5) * cell.ddx(1) + (0.5 - yj) * cell.ddx(2);
+    hxm = (yj + 0.5) * cell.ddx(4) + (0.5 - yj) * cell.ddx(5);
   }
   double ssh_x = xi * hxp + (1. - xi) * hxm;
-  const double ddy_00 = t0.ddy, ddy_0m = g.trc[c - g.ni].ddy;
   if (xi >= 0.5) {
-    hxp = (xi - 0.5) * g.trc[c + 1].ddy + (1.5 - xi) * ddy_00;
-    hxm = (xi - 0.5) * g.trc[c + 1 - g.ni].ddy + (1.5 - xi) * ddy_0m;
+    hxp = (xi - 0.5) * cell.ddy(0) + (1.5 - xi) * cell.ddy(1);
+    hxm = (xi - 0.5) * cell.ddy(3) + (1.5 - xi) * cell.ddy(4);
   } else {
-    hxp = (xi + 0.5) * ddy_00 + (0.5 - xi) * g.trc[c - 1].ddy;
-    hxm = (xi + 0.5) * ddy_0m + (0.5 - xi) * g.trc[c - 1 - g.ni].ddy;
+    hxp = (xi + 0.5) * cell.ddy(1) + (0.5 - xi) * cell.ddy(2);
+    hxm = (xi + 0.5) * cell.ddy(4) + (0.5 - xi) * cell.ddy(5);
   }
   double ssh_y = yj * hxp + (1. - yj) * hxm;
   // rotate to lat-lon (IB:4953-4967)
@@ -269,7 +347,7 @@ __device__ __forceinline__ void interp_flds(const DevGrid &g, const kid_params &
   if (ssh_x != ssh_x) ssh_x = 0.;
   if (ssh_y != ssh_y) ssh_y = 0.;
   e.uo = uo; e.vo = vo; e.ui = ui; e.vi = vi; e.ua = ua; e.va = va; e.ssh_x = ssh_x; e.ssh_y = ssh_y;
-  e.sst = t0.sst; e.sss = t0.sss; e.cn = t0.cn; e.hi = t0.hi; e.od = t0.od;
+  e.sst = cell.t0(0); e.sss = cell.t0(1); e.cn = cell.t0(2); e.hi = cell.t0(3); e.od = cell.t0(4);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -399,7 +477,7 @@ __device__ __noinline__ void adjust_index_slow(const DevGrid &g, const kid_param
       if (yj < 0.) yj = posn_eps;
       bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
     }
-    lret = pos_within_cell<false>(g, p, lon, lat, i, j, xi, yj, err, unused_bail);
+    lret = pos_within_cell<false>(g, p, GlbCell{g, g.idx(i, j)}, lon, lat, i, j, xi, yj, err, unused_bail);
   }
   if (!bounced && lret && g.geo[g.idx(i, j)].msk > 0.) return;
   if (!bounced && !lret) {
@@ -413,12 +491,12 @@ __device__ __noinline__ void adjust_index_slow(const DevGrid &g, const kid_param
   if (yj > 1.) yj = 1. - posn_eps;
   if (yj <= 0.) yj = posn_eps;
   bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
-  (void)pos_within_cell<false>(g, p, lon, lat, i, j, xi, yj, err, unused_bail);
+  (void)pos_within_cell<false>(g, p, GlbCell{g, g.idx(i, j)}, lon, lat, i, j, xi, yj, err, unused_bail);
 }
 template <bool FAST>
-__device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, double &lon, double &lat,
+__device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, const lds_double *pk, double &lon, double &lat,
                                                         int &i, int &j, double &xi, double &yj, int &err, bool &bail) {
-  if (pos_within_cell<FAST>(g, p, lon, lat, i, j, xi, yj, err, bail)) return;  // the common case: still in its cell
+  if (pos_within_cell<FAST>(g, p, CellOf<FAST>::make(g, pk, i, j), lon, lat, i, j, xi, yj, err, bail)) return;  // the common case: still in its cell
   if (FAST) bail = true;
   else adjust_index_slow(g, p, lon, lat, i, j, xi, yj, err);
 }
@@ -478,7 +556,7 @@ struct BergDyn {
 // ---------------------------------------------------------------------------------------------------------
 template <bool OLD_ORDER, bool FAST>
 __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
-                                         BergDyn &d, unsigned &tickets, int &err, bool &bail) {
+                                         BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
   const double dt = p.dt, dt_2 = 0.5 * dt, dt_6 = dt / 6.;
   const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
   const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
@@ -496,16 +574,21 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   int i = i1, j = j1; double xi = xi1, yj = yj1;
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
-    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST>(g, p, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
+    KID_MARK("loop_top");
+    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
     KID_PHASE_FENCE();
+    KID_MARK("after_adjust");
     const LatTerms lt = lat_terms(g, p, lat_s, sin_ref);
     double qu = uvel_s * lt.dxdl, qv = vvel_s * dydl;          // u_k, v_k  IB:7412
     KID_PHASE_FENCE();
     double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
-    if (OLD_ORDER) interp_flds(g, p, i, j, xi, yj, e);
+    KID_MARK("after_latterms");
+    if (OLD_ORDER) interp_flds(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e);
     KID_PHASE_FENCE();
+    KID_MARK("after_interp");
     accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel_s, vvel_s, uvel1, vvel1, (s < 2) ? dt_2 : dt, ax, ay, axn_s, ayn_s, bxn, byn, tickets);
     KID_PHASE_FENCE();
+    KID_MARK("after_accel");
     double qax = ax, qay = ay, qaxn = axn_s, qayn = ayn_s;
     if (on_tang) {
       qu = xdot_s; qv = ydot_s;
@@ -529,6 +612,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
       }
     }
   }
+  KID_MARK("loop_end");
   // combine IB:7597-7616
   double lonn, latn, uveln, vveln, axn, ayn;
   if (on_tang) {
@@ -550,7 +634,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   }
   i = i1; j = j1; xi = xi1; yj = yj1;
   KID_PHASE_FENCE();
-  adjust_index_and_ground<FAST>(g, p, lonn, latn, i, j, xi, yj, err, bail);
+  adjust_index_and_ground<FAST>(g, p, pk, lonn, latn, i, j, xi, yj, err, bail);
   if (p.override_iceberg_velocities) { uveln = p.u_override; vveln = p.v_override; }  // IB:7151-7154
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
   d.xi = xi; d.yj = yj; d.ine = i; d.jne = j;
@@ -561,7 +645,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
 // ---------------------------------------------------------------------------------------------------------
 template <bool OLD_ORDER, bool FAST>
 __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
-                                            BergDyn &d, unsigned &tickets, int &err, bool &bail) {
+                                            BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
   const double dt = p.dt, dt_2 = 0.5 * dt;
   const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
   const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
@@ -571,7 +655,7 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
   const double uvel3 = uvel1 + (dt_2 * axn), vvel3 = vvel1 + (dt_2 * ayn);         // IB:7259-7260
   const LatTerms lt = lat_terms(g, p, lat1, sin_ref);
   Env e = stored;
-  if (OLD_ORDER) interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e);
+  if (OLD_ORDER) interp_flds(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e);
   KID_PHASE_FENCE();
   double ax1, ay1, uveln, vveln;
   accel<false>(g, p, bg, e, d.ine, d.jne, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt, ax1, ay1, axn, ayn, bxn, byn, tickets);
@@ -597,7 +681,7 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
     lonn = lon1 + (dt * u2); latn = lat1 + (dt * v2);
   }
   KID_PHASE_FENCE();
-  adjust_index_and_ground<FAST>(g, p, lonn, latn, d.ine, d.jne, d.xi, d.yj, err, bail);
+  adjust_index_and_ground<FAST>(g, p, pk, lonn, latn, d.ine, d.jne, d.xi, d.yj, err, bail);
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
 }
 

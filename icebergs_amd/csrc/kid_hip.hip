@@ -91,11 +91,17 @@ __global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec
 // Keeping the rare branches out of the hot build roughly halves its register footprint (2 waves/SIMD, no scratch).
 struct Redo { int *list; int *count; };
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST>
-__global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(const DevGrid g, const kid_params p, const BergPtrs b, const long long n,
+__global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(const DevGrid g, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
                                                    double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
+  // The parameter block (142 dwords) and the 51 field pointers are read through device-memory tables on demand:
+  // as by-value kernel arguments they were all pinned in SGPRs, overflowed the scalar file and came back as
+  // thousands of v_readlane spill reloads per wave.
+  const kid_params &p = *pp;
+  const BergPtrs &b = *bt;
   constexpr bool SCATTER = (PH & (PH_THERMO | PH_SPREAD)) != 0;
-  __shared__ double lds_vals[SCATTER ? KID_SEG_LDS_DOUBLES : 1];
-  __shared__ int lds_ints[SCATTER ? KID_SEG_LDS_INTS : 1];
+  __shared__ double lds_vals[SCATTER ? KID_SEG_LDS_DOUBLES : 1];   // staging of the per-cell sums (kid_thermo.hpp)
+  __shared__ int lds_ints[KID_SEG_LDS_INTS];                         // run tables of the 4 waves
+  __shared__ double lds_pk[FAST ? 4 * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the 4 waves (hot build)
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
   const long long total = FAST ? n : (long long)(*redo.count);
   for (long long tid = (long long)blockIdx.x * 256ll + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * 256ll + threadIdx.x) : (tid - threadIdx.x < total));
@@ -109,6 +115,29 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
 
   BergDyn d;
   d.ine = b.i[KID_BI_INE][kk]; d.jne = b.i[KID_BI_JNE][kk];
+  // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
+  Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);
+  const lds_double *pk = nullptr;
+  if (FAST) {
+    if (seg.R > KID_MAXRUN) {  // an unsorted wave: no packet sharing to be had, the general build takes all of it
+      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; }
+      continue;
+    }
+    lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (KID_MAXRUN * PK_STRIDE);
+    const int lane = (int)__lane_id();
+    // lane q fetches packet elements q and q+64 of every distinct cell: where they live is fixed per lane
+    const PacketSrc s0 = packet_source(g, lane), s1 = packet_source(g, (lane < PK_SIZE - 64) ? 64 + lane : 0);
+    for (int r = 0; r < seg.R; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
+      const int c = seg.cell[r];
+      if (c >= 0) {
+        wpk[r * PK_STRIDE + lane] = *reinterpret_cast<const double *>(s0.base + (long long)c * s0.stride);
+        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = *reinterpret_cast<const double *>(s1.base + (long long)c * s1.stride);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    pk = wpk + (__popcll(seg.heads & le) - 1) * PK_STRIDE;
+  }
   d.xi = b.f[KID_B_XI][kk]; d.yj = b.f[KID_B_YJ][kk];
   d.lon = b.f[KID_B_LON][kk]; d.lat = b.f[KID_B_LAT][kk];
   d.uvel = b.f[KID_B_UVEL][kk]; d.vvel = b.f[KID_B_VVEL][kk];
@@ -128,7 +157,7 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
 
   if ((PH & PH_INTERP) || (!OLD_ORDER && (PH & (PH_EVOLVE | PH_THERMO)))) {
     if (PH & PH_INTERP) {  // IB:4673-4715
-      if (was_alive && !halo) { interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e); env_dirty = true; }
+      if (was_alive && !halo) { interp_flds(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e); env_dirty = true; }
     } else {  // stored environment (.not.old_interp_flds_order), IB:2039-2040
       e.uo = b.f[KID_B_UO][kk]; e.vo = b.f[KID_B_VO][kk]; e.ui = b.f[KID_B_UI][kk]; e.vi = b.f[KID_B_VI][kk];
       e.ua = b.f[KID_B_UA][kk]; e.va = b.f[KID_B_VA][kk]; e.ssh_x = b.f[KID_B_SSH_X][kk]; e.ssh_y = b.f[KID_B_SSH_Y][kk];
@@ -142,8 +171,8 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
     const bool moves = was_alive && (t.static_berg < 0.5);
     if (moves) {
       const BergGeom bg{t.M, t.T, t.W, t.L, t.n_bonds};
-      if (RK) rk4_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail);
-      else verlet_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail);
+      if (RK) rk4_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail, pk);
+      else verlet_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail, pk);
       if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
         const int slot = atomicAdd(redo.count, 1);
         redo.list[slot] = (int)kk;
@@ -166,10 +195,12 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
     }
   }
   KID_PHASE_FENCE();
+  KID_MARK("evolve_done");
 
   if (PH & (PH_THERMO | PH_SPREAD)) {
     const bool active = t.alive && !skipped;
-    Seg seg = make_runs(active ? g.idx(d.ine, d.jne) : (-1 - (int)__lane_id()), (lds_double *)lds_vals, (lds_int *)lds_ints);
+    if (!FAST) seg = make_runs(active ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);  // cells may have changed
+    const typename CellOf<FAST>::type cellv = CellOf<FAST>::make(g, pk, d.ine, d.jne);
     t.mass_scaling = b.f[KID_B_MASS_SCALING][kk];
     t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk];
     t.heat_density = (PH & PH_THERMO) ? b.f[KID_B_HEAT_DENSITY][kk] : 0.;
@@ -182,12 +213,13 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
     if (PH & PH_THERMO) {
       if (OLD_ORDER || (!p.mts && !p.dem && halo)) {  // IB:2890-2894 (od is not passed there)
         const double od_keep = e.od;
-        if (active) { interp_flds(g, p, d.ine, d.jne, d.xi, d.yj, e); env_dirty = true; }
+        if (active) { interp_flds(p, cellv, d.xi, d.yj, e); env_dirty = true; }
         if (PH & PH_INTERP) e.od = od_keep;
       }
       KID_PHASE_FENCE();
+      KID_MARK("thermo_interp_done");
       const BergThermo before = t;
-      thermodynamics(g, p, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
+      thermodynamics(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
       if (active) {
         b.f[KID_B_MASS][kk] = t.M; b.f[KID_B_THICKNESS][kk] = t.T; b.f[KID_B_WIDTH][kk] = t.W; b.f[KID_B_LENGTH][kk] = t.L;
         if (t.mass_of_bits != before.mass_of_bits) b.f[KID_B_MASS_OF_BITS][kk] = t.mass_of_bits;
@@ -201,14 +233,16 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
         }
       }
       KID_PHASE_FENCE();
+      KID_MARK("thermo_done");
     }
     if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
       const bool act2 = t.alive && !skipped;
       if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
-        spread_mass(g, p, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg);
-      berg_diagnostics(g, p, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
+        spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg);
+      berg_diagnostics(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
     seg_flush(seg, acc, ncell);
+    KID_MARK("spread_done");
   }
 
   if (was_alive && !skipped) {
@@ -326,6 +360,9 @@ struct kid_handle {
   double *d_out = nullptr;                        // KID_NOUT*ncell
   double *d_totals = nullptr;                     // KID_NSCALAR running totals (the block's scalars are per-step)
   BergPtrs bp{};
+  BergPtrs *d_bp = nullptr;      // device copy of the field-pointer table
+  kid_params *d_params = nullptr; // device copy of the parameter block
+  bool tables_dirty = true;
   double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
   unsigned long long *d_count = nullptr;
   int *d_redo_list = nullptr, *d_redo_count = nullptr;  // bergs the FAST build hands to the general build
@@ -422,6 +459,8 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   for (int f = 0; f < KID_NB_I32; ++f) { KID_HIP(h, hipMalloc(&h->bp.i[f], (size_t)capacity * sizeof(int32_t))); KID_HIP(h, hipMemset(h->bp.i[f], 0, (size_t)capacity * sizeof(int32_t))); }
   KID_HIP(h, hipMalloc(&h->bp.id, (size_t)capacity * sizeof(int64_t)));
   KID_HIP(h, hipMemset(h->bp.id, 0, (size_t)capacity * sizeof(int64_t)));
+  KID_HIP(h, hipMalloc(&h->d_bp, sizeof(BergPtrs)));
+  KID_HIP(h, hipMalloc(&h->d_params, sizeof(kid_params)));
   KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
   KID_HIP(h, hipMalloc(&h->d_redo_list, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipMalloc(&h->d_redo_count, sizeof(int)));
@@ -450,6 +489,8 @@ int kid_destroy(kid_handle *h) {
   if (h->d_flag) (void)hipFree(h->d_flag);
   if (h->d_scan_tmp) (void)hipFree(h->d_scan_tmp);
   if (h->d_count) (void)hipFree(h->d_count);
+  if (h->d_bp) (void)hipFree(h->d_bp);
+  if (h->d_params) (void)hipFree(h->d_params);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
   if (h->d_redo_count) (void)hipFree(h->d_redo_count);
   for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
@@ -467,6 +508,7 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   int rc = check_params(h, params);
   if (rc) return rc;
   h->params = *params;
+  h->tables_dirty = true;
   return KID_OK;
 }
 int kid_set_stream(kid_handle *h, void *s) {
@@ -550,6 +592,15 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   }
   if (host->id) KID_HIP(h, hipMemcpyAsync(h->bp.id, host->id, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
   else KID_HIP(h, hipMemsetAsync(h->bp.id, 0, n * sizeof(int64_t), h->stream));
+  // cell indices are trusted by the kernels: reject anything outside the computational domain + first halo row
+  if (host->i32[KID_BI_INE] && host->i32[KID_BI_JNE]) {
+    for (size_t k = 0; k < n; ++k) {
+      const int i = host->i32[KID_BI_INE][k], j = host->i32[KID_BI_JNE][k];
+      if (i < h->gd.isc - 1 || i > h->gd.iec + 1 || j < h->gd.jsc - 1 || j > h->gd.jec + 1) {
+        h->err = "berg cell index (ine,jne) outside the computational domain"; return KID_EINVAL;
+      }
+    }
+  } else if (n > 0) { h->err = "ine/jne are required"; return KID_EINVAL; }
   // which optional per-berg fields can matter at all (avoids streaming all-zero arrays through the kernel)
   for (size_t k = 0; k < n; ++k) {
     if (host->f64[KID_B_STATIC_BERG] && host->f64[KID_B_STATIC_BERG][k] != 0.) any_static = true;
@@ -635,6 +686,7 @@ int kid_compact_bergs(kid_handle *h) {
   KID_HIP(h, hipGetLastError());
   KID_HIP(h, hipStreamSynchronize(h->stream));
   h->n = n_alive;
+  h->tables_dirty = true;
   return KID_OK;
 }
 
@@ -663,16 +715,21 @@ static int launch_berg(kid_handle *h) {
     KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1));
     KID_HIP(h, hipEventRecord(e0, h->stream));
   }
-const Redo redo{h->d_redo_list, h->d_redo_count};
+if (h->tables_dirty) {  // refresh the device-side tables (pageable host source: effectively synchronous)
+    KID_HIP(h, hipMemcpyAsync(h->d_bp, &h->bp, sizeof(BergPtrs), hipMemcpyHostToDevice, h->stream));
+    KID_HIP(h, hipMemcpyAsync(h->d_params, &h->params, sizeof(kid_params), hipMemcpyHostToDevice, h->stream));
+    KID_HIP(h, hipStreamSynchronize(h->stream));
+    h->tables_dirty = false;
+  }
+  const Redo redo{h->d_redo_list, h->d_redo_count};
   KID_HIP(h, hipMemsetAsync(h->d_redo_count, 0, sizeof(int), h->stream));
   // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
   // (a few per cent: cell crossings, coast bounces, polar cells).  Pass 2 is sized for the worst case and its
   // surplus workgroups exit on the device-side count.
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nb), dim3(256), 0, h->stream, g, h->params, h->bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
-    if (PH & PH_EVOLVE)                                                                                                         \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nb < 512u ? nb : 512u), dim3(256), 0, h->stream, g, h->params, h->bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nb), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nb < 512u ? nb : 512u), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
   } while (0)
   if (rk && old) KID_LAUNCH(true, true);
   else if (rk && !old) KID_LAUNCH(true, false);

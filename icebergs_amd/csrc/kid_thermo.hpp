@@ -23,15 +23,15 @@ namespace kid {
 //   * seg_flush(): the (slot, run) pairs are dealt to the lanes, each lane sums its run's staged values in lane
 //     order (a fixed order: bitwise reproducible within a wave) and issues ONE atomic for the run.
 // That is ~14x fewer atomics and, unlike a shuffle scan, costs about one LDS write + one LDS read per value.
+constexpr int KID_MAXRUN = 16;  // the hot build shares at most this many cell packets per wave
 constexpr int KID_CHUNK = 12;  // staged values per flush: 6 KB of LDS per wave
-typedef __attribute__((address_space(3))) double lds_double;
-typedef __attribute__((address_space(3))) int lds_int;
 struct Seg {
   lds_double *val;   // [KID_CHUNK][64] staging, this wave
   lds_int *head;     // [64] first lane of run r
   lds_int *len;      // [64] length of run r
   lds_int *cell;     // [64] cell index of run r (<0: inactive lanes, nothing to add)
   lds_int *plane;    // [KID_CHUNK] plane id of staged slot
+  unsigned long long heads;  // bit l: lane l starts a run
   int R;             // number of runs in this wave
   unsigned M;        // ceil(65536 / R): item / R == (item * M) >> 16 for item < 1024
   int npend;         // staged slots (wave-uniform)
@@ -54,6 +54,7 @@ __device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *int
   const int prev = __shfl_up(key, 1);
   const bool is_head = (lane == 0) || (prev != key);
   const unsigned long long heads = __ballot(is_head);
+  s.heads = heads;
   s.R = __popcll(heads);
   s.M = (65536u + (unsigned)s.R - 1u) / (unsigned)s.R;
   if (is_head) {
@@ -116,7 +117,8 @@ __device__ __forceinline__ int minloc_abs10(const double *tab, double v) {  // F
 }
 
 // IB:2844-3300 thermodynamics for one berg.  Writes the new state into `b`, scatters into acc planes.
-__device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_params &p, BergThermo &b, const Env &e,
+template <class CELL>
+__device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_params &p, const CELL &cellv, BergThermo &b, const Env &e,
                                                double uvel, double vvel, double lat, int i, int j, bool active,
                                                double *acc, size_t ncell, Seg &seg, double *scal) {
   constexpr double perday = 1. / 86400.;
@@ -238,7 +240,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
     } else { dMbitsE_fl = 0.; dMbitsM_fl = 0.; nMbits_fl = 0.; }
   }
   // per-cell accumulation IB:3114-3208
-  const double area = g.geo[c].area, ms = b.mass_scaling;
+  const double area = cellv.area(), ms = b.mass_scaling;
   const bool ok = active && (area != 0.);
   const int dm = p.diag_mask;
 #define KID_ACC(F, v) cell_add(acc, ncell, (F), c, (v), seg, ok)
@@ -425,11 +427,12 @@ __device__ __noinline__ void hexagon_into_quadrants(const kid_params &p, double 
 // ---------------------------------------------------------------------------------------------------------
 // IB:3895-4133 spread_mass_across_ocean_cells + calculate_sum_over_bergs_diagnositcs (IB:5014-5071)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const BergThermo &b, double uvel, double vvel,
+template <class CELL>
+__device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
                                             int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg) {
   constexpr double rho_sw = 1035.;  // IB:3919 shadows the module's 1025
   const int c = g.idx(i, j);
-  const double a_ij = g.geo[c].area;
+  const double a_ij = cellv.area();
   const bool ok = active && (a_ij > 0.);  // IB:4994
   const double Area = b.L * b.W, Tn = b.T, scaling = b.mass_scaling;
   double Mass_berg = b.M, Mfl = b.mass_of_fl_bits;
@@ -449,7 +452,7 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   if (p.clipping_depth > 0.) Mass = dmin(Mass, p.clipping_depth * a_ij * rho_sw);
   double w[9] = {0., 0., 0., 0., 1., 0., 0., 0., 0.};  // yDxL,yDxC,yDxR,yCxL,yCxC,yCxR,yUxL,yUxC,yUxR
   double fraction_used = 1.;
-#define KID_M(di, dj) g.geo[c + (di) + (dj) * g.ni].msk
+#define KID_M(di, dj) cellv.msk((di), (dj))
   if (!p.hexagonal_icebergs) {
     const double L = (a_ij > 0) ? dmin(sqrt(Area / a_ij), 1.0) : 1.;
     double xL, xR, xC, yD, yU, yC;
@@ -491,10 +494,11 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   }
 }
 
-__device__ __forceinline__ void berg_diagnostics(const DevGrid &g, const kid_params &p, const BergThermo &b, double uvel, double vvel,
+template <class CELL>
+__device__ __forceinline__ void berg_diagnostics(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
                                                  int i, int j, bool active, double *acc, size_t ncell, Seg &seg) {
   const int c = g.idx(i, j);
-  const double area = g.geo[c].area, ms = b.mass_scaling;
+  const double area = cellv.area(), ms = b.mass_scaling;
   const bool ok = active && (area > 0.);
   const int dm = p.diag_mask;
 #define KID_ACC(F, v) cell_add(acc, ncell, (F), c, (v), seg, ok)

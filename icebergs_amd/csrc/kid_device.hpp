@@ -134,17 +134,18 @@ __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : 
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double sign1(double b) { return copysign(1.0, b); }
 
-// Fortran MODULO(a,p), p>0 (FW:6568).  Longitudes handed to it are within one period of the window almost
-// always, where the exact result needs no division; the general case falls back to fmod.
-__device__ __forceinline__ double f_modulo(double a, double p) {
-  if (a >= 0.0) {
-    if (a < p) return a;
-    if (a < 2.0 * p) return a - p;  // exact (Sterbenz)
-  } else if (a > -p) {
-    return a + p;
-  }
+// Fortran MODULO(a,p), p>0 (FW:6568).  A longitude handed to it lies inside the window [0,p) in all but the
+// rarest cases, where the exact result is the argument itself; everything else goes out of line.
+__device__ __noinline__ double f_modulo_slow(double a, double p) {
+  if (a >= 0.0) { if (a < 2.0 * p) return a - p; }  // exact (Sterbenz)
+  else if (a > -p) return a + p;
   double r = fmod(a, p);
   if (r != 0.0 && (r < 0.0)) r += p;
+  return r;
+}
+__device__ __forceinline__ double f_modulo(double a, double p) {
+  double r = a;
+  if (__builtin_expect(!(a >= 0.0 && a < p), 0)) r = f_modulo_slow(a, p);
   return r;
 }
 __device__ __forceinline__ double mod_around(double x, double y, double Lx) {  // FW:6558-6573
@@ -196,11 +197,11 @@ __device__ __forceinline__ bool is_point_in_cell(const DevGrid &g, const Corners
   const double c = mod_around(q.lon01, x, Lx), d = mod_around(q.lon11, x, Lx);
   const double xlo = dmin(dmin(dmin(a, b), c), d), xhi = dmax(dmax(dmax(a, b), c), d);
   const double tol = 0.1;
-  if (x < (xlo - tol) || x > (xhi + tol)) return false;
   const double ylo = dmin(dmin(dmin(q.lat00, q.lat10), q.lat01), q.lat11);
   const double yhi = dmax(dmax(dmax(q.lat00, q.lat10), q.lat01), q.lat11);
-  if (y < ylo || y > yhi) return false;
-  if (!FAST && g.latlon && yhi > 89.999) {  // one corner at the pole: five-sided polygon (cold path; FAST bails earlier)
+  // the reference returns early on the crude bounds (FW:6118, 6122); evaluated without branches here
+  const bool crude = !(x < (xlo - tol) || x > (xhi + tol)) && !(y < ylo || y > yhi);
+  if (!FAST && crude && g.latlon && yhi > 89.999) {  // one corner at the pole: five-sided polygon (cold path; FAST bails earlier)
     if (q.lat11 > 89.999)
       return sum_sign_dot_prod5(q.lon00, q.lat00, q.lon10, q.lat10, q.lon10, q.lat11, q.lon01, q.lat11, q.lon01, q.lat01, x, y, Lx);
     else if (q.lat01 > 89.999)
@@ -210,7 +211,7 @@ __device__ __forceinline__ bool is_point_in_cell(const DevGrid &g, const Corners
     else if (q.lat10 > 89.999)
       return sum_sign_dot_prod5(q.lon00, q.lat00, q.lon00, q.lat10, q.lon11, q.lat10, q.lon11, q.lat11, q.lon01, q.lat01, x, y, Lx);
   }
-  return sum_sign_dot_prod4(q.lon00, q.lat00, q.lon10, q.lat10, q.lon11, q.lat11, q.lon01, q.lat01, x, y, Lx);
+  return crude & sum_sign_dot_prod4(q.lon00, q.lat00, q.lon10, q.lat10, q.lon11, q.lat11, q.lon01, q.lat01, x, y, Lx);
 }
 
 // FW:6439-6534.  Returns false on the reference's FATAL paths.

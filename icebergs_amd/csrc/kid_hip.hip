@@ -265,7 +265,10 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
 __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_params p, double *__restrict__ acc,
                                                      double *__restrict__ out, const size_t ncell, double *__restrict__ totals) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < KID_NSCALAR) totals[t] += acc[(size_t)KID_NACC * ncell + t];  // running totals kept on `bergs` (IB:3130, 3295)
+  if (t < KID_NSCALAR) {  // fold this step's increments into the running totals kept on `bergs` (IB:3130, 3295)
+    totals[t] += acc[(size_t)KID_NACC * ncell + t];
+    acc[(size_t)KID_NACC * ncell + t] = 0.;
+  }
   const int nic = g.iec - g.isc + 1, njc = g.jec - g.jsc + 1;
   if (t >= nic * njc) return;
   const int i = g.isc + t % nic, j = g.jsc + t / nic;
@@ -523,12 +526,21 @@ int kid_sync(kid_handle *h) {
   return KID_OK;
 }
 
-static int repack(kid_handle *h) {
+static int pack_static(kid_handle *h) {
   GridPlanes gp;
   for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
   for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = h->d_forcing[k];
   const int nb = (int)((h->ncell + 255) / 256);
   hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, (int)h->ncell);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
+// src[k]: where forcing plane k currently lives on the device (the handle's own copy, or the caller's buffer)
+static int pack_forcing(kid_handle *h, const double *const src[KID_NFORCING]) {
+  GridPlanes gp;
+  for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
+  for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = src[k] ? src[k] : h->d_forcing[k];
+  const int nb = (int)((h->ncell + 255) / 256);
   hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_vel, h->d_trc, h->ni, h->nj);
   KID_HIP(h, hipGetLastError());
   return KID_OK;
@@ -542,7 +554,10 @@ int kid_set_static_grid(kid_handle *h, const double *const fields[KID_NGRID_STAT
     KID_HIP(h, hipMemcpyAsync(h->d_static[k], fields[k], h->ncell * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
   h->have_static = true;
-  int rc = repack(h);
+  int rc = pack_static(h);
+  if (rc) return rc;
+  const double *none[KID_NFORCING] = {};
+  rc = pack_forcing(h, none);
   if (rc) return rc;
   KID_HIP(h, hipStreamSynchronize(h->stream));
   return KID_OK;
@@ -557,7 +572,8 @@ int kid_set_forcing(kid_handle *h, const double *const fields[KID_NFORCING]) {
     KID_HIP(h, hipMemcpyAsync(h->d_forcing[k], fields[k], h->ncell * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
   h->have_forcing = true;
-  int rc = repack(h);
+  const double *none[KID_NFORCING] = {};
+  int rc = pack_forcing(h, none);
   if (rc) return rc;
   KID_HIP(h, hipStreamSynchronize(h->stream));  // the host arrays may be reused by the caller
   return KID_OK;
@@ -567,12 +583,12 @@ int kid_set_forcing_device(kid_handle *h, const double *const fields[KID_NFORCIN
   if (!h || !fields) return KID_EINVAL;
   if (!h->have_static) { h->err = "kid_set_static_grid must be called first"; return KID_EINVAL; }
   KID_HIP(h, hipSetDevice(h->device));
-  for (int k = 0; k < KID_NFORCING; ++k) {
-    if (!fields[k]) continue;
-    KID_HIP(h, hipMemcpyAsync(h->d_forcing[k], fields[k], h->ncell * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  }
+  // The per-cell records are built straight from the caller's planes; only ssh is also kept as a plane (the
+  // grounding_fraction path of the mass spreading reads it, IB:3942).
+  if (fields[KID_F_SSH])
+    KID_HIP(h, hipMemcpyAsync(h->d_forcing[KID_F_SSH], fields[KID_F_SSH], h->ncell * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   h->have_forcing = true;
-  return repack(h);
+  return pack_forcing(h, fields);
 }
 
 int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
@@ -696,8 +712,7 @@ int kid_zero_accumulators(kid_handle *h) {
   const size_t planes = (size_t)nacc_active(h);
   KID_HIP(h, hipMemsetAsync(h->d_acc, 0, planes * h->ncell * sizeof(double), h->stream));
   // the KID_NSCALAR words behind the planes hold this step's increments of the running totals the reference
-  // keeps on `bergs` (net_heat_to_ocean, nbergs_melted, ...); the gather folds them into the totals.
-  KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_NACC * h->ncell, 0, KID_NSCALAR * sizeof(double), h->stream));
+  // keeps on `bergs` (net_heat_to_ocean, nbergs_melted, ...); the gather folds them into the totals and clears them.
   return KID_OK;
 }
 
@@ -769,8 +784,6 @@ static int launch_gather(kid_handle *h) {
   const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell, h->d_totals);
   KID_HIP(h, hipGetLastError());
-  // the step's increments are now folded into the totals
-  KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_NACC * h->ncell, 0, KID_NSCALAR * sizeof(double), h->stream));
   return KID_OK;
 }
 int kid_create_gridded_icebergs_fields(kid_handle *h) {

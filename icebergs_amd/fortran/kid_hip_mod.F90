@@ -1,0 +1,168 @@
+!> ISO_C_BINDING shim over libkid_hip.so (include/kid.h): the Fortran host side of the MI355X evolve loop.
+!!
+!! The reference host is Fortran (icebergs_init / icebergs_run in src/icebergs.F90:92-178, 5074-5887) and stays
+!! Fortran: this module is all a Fortran caller needs to drive the HIP kernels.  Each wrapper maps one call site of
+!! icebergs_run to one C-ABI entry point (see the table in include/kid.h) and turns a non-zero status into the
+!! reference's abort-on-error convention through kid_check (the reference calls error_mesg(...,FATAL), e.g.
+!! icebergs.F90:3207; here `error stop`, so that the module has no FMS dependency).
+!! The derived types and enum constants are generated from include/kid_types.h (tools/gen_fortran_types.py).
+module kid_hip_mod
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  include 'kid_types_gen.inc'
+
+  integer(c_int), parameter, public :: KID_OK = 0, KID_EINVAL = -1, KID_EHIP = -2, KID_ENODEV = -3, &
+                                       KID_ECAPACITY = -4, KID_EUNSUPPORTED = -5
+
+  public :: kid_grid_desc, kid_params, kid_berg_soa
+  public :: kid_create, kid_destroy, kid_set_params, kid_sync, kid_set_static_grid, kid_set_forcing
+  public :: kid_upload_bergs, kid_download_bergs, kid_num_bergs, kid_compact_bergs
+  public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
+  public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
+  public :: kid_get_accumulators, kid_last_error_f, kid_check
+  public :: KID_NGRID_STATIC, KID_NFORCING, KID_NB_F64, KID_NB_I32, KID_NACC, KID_NOUT, KID_NSCALAR
+  public :: KID_B_LON, KID_B_LAT, KID_B_UVEL, KID_B_VVEL, KID_B_MASS, KID_B_THICKNESS, KID_B_WIDTH, KID_B_LENGTH
+  public :: KID_B_XI, KID_B_YJ, KID_BI_INE, KID_BI_JNE, KID_BI_ALIVE
+  public :: KID_A_FLOATING_MELT, KID_A_BERG_MELT, KID_A_CALVING_HFLX, KID_O_SPREAD_MASS
+  public :: KID_S_NET_HEAT_TO_OCEAN, KID_S_NBERGS_MELTED, KID_S_NBERGS_ALIVE
+
+  interface
+    integer(c_int) function kid_create(grid, params, capacity, device, handle) bind(C, name='kid_create')
+      import :: c_int, c_int64_t, c_ptr, kid_grid_desc, kid_params
+      type(kid_grid_desc), intent(in) :: grid
+      type(kid_params), intent(in) :: params
+      integer(c_int64_t), value :: capacity
+      integer(c_int), value :: device
+      type(c_ptr), intent(out) :: handle
+    end function
+    integer(c_int) function kid_destroy(h) bind(C, name='kid_destroy')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_set_params(h, params) bind(C, name='kid_set_params')
+      import :: c_int, c_ptr, kid_params
+      type(c_ptr), value :: h
+      type(kid_params), intent(in) :: params
+    end function
+    integer(c_int) function kid_sync(h) bind(C, name='kid_sync')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    !> fields(KID_NGRID_STATIC): c_loc of grd%lon, grd%lat, grd%lonc, ... (KID_G_* order), each (isd:ied,jsd:jed)
+    integer(c_int) function kid_set_static_grid(h, fields) bind(C, name='kid_set_static_grid')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      type(c_ptr), intent(in) :: fields(*)
+    end function
+    !> fields(KID_NFORCING): c_loc of grd%uo, grd%vo, ... after the ingest block of icebergs_run (IB:5236-5383)
+    integer(c_int) function kid_set_forcing(h, fields) bind(C, name='kid_set_forcing')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      type(c_ptr), intent(in) :: fields(*)
+    end function
+    integer(c_int) function kid_upload_bergs(h, soa) bind(C, name='kid_upload_bergs')
+      import :: c_int, c_ptr, kid_berg_soa
+      type(c_ptr), value :: h
+      type(kid_berg_soa), intent(in) :: soa
+    end function
+    integer(c_int) function kid_download_bergs(h, soa) bind(C, name='kid_download_bergs')
+      import :: c_int, c_ptr, kid_berg_soa
+      type(c_ptr), value :: h
+      type(kid_berg_soa), intent(inout) :: soa
+    end function
+    integer(c_int) function kid_num_bergs(h, n_slots, n_alive) bind(C, name='kid_num_bergs')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: n_slots, n_alive
+    end function
+    integer(c_int) function kid_compact_bergs(h) bind(C, name='kid_compact_bergs')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_zero_accumulators(h) bind(C, name='kid_zero_accumulators')          ! IB:5125-5156
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_interp_gridded_fields_to_bergs(h) bind(C, name='kid_interp_gridded_fields_to_bergs') ! IB:5423
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_evolve_icebergs(h) bind(C, name='kid_evolve_icebergs')              ! IB:5433
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_footloose_calving(h) bind(C, name='kid_footloose_calving')          ! IB:5453
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_thermodynamics(h) bind(C, name='kid_thermodynamics')                ! IB:5505
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_create_gridded_icebergs_fields(h) bind(C, name='kid_create_gridded_icebergs_fields') ! IB:5512
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_step_local(h) bind(C, name='kid_step_local')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_step_gather(h) bind(C, name='kid_step_gather')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_run_step(h, nsteps) bind(C, name='kid_run_step')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: nsteps
+    end function
+    integer(c_int) function kid_get_accumulators(h, acc, out, scalars) bind(C, name='kid_get_accumulators')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      type(c_ptr), value :: acc, out, scalars
+    end function
+    type(c_ptr) function kid_last_error(h) bind(C, name='kid_last_error')
+      import :: c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_size_t) function c_strlen(s) bind(C, name='strlen')
+      import :: c_ptr, c_size_t
+      type(c_ptr), value :: s
+    end function
+  end interface
+
+contains
+
+  !> The library's last error message as a Fortran string
+  function kid_last_error_f(h) result(msg)
+    type(c_ptr), intent(in) :: h
+    character(len=:), allocatable :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: chars(:)
+    integer :: n, k
+    p = kid_last_error(h)
+    msg = ''
+    if (.not. c_associated(p)) return
+    n = int(c_strlen(p))
+    if (n <= 0) return
+    call c_f_pointer(p, chars, [n])
+    allocate(character(len=n) :: msg)
+    do k = 1, n
+      msg(k:k) = chars(k)
+    end do
+  end function
+
+  !> Abort on a non-zero status: the reference's error_mesg(...,FATAL) convention (e.g. icebergs.F90:3207)
+  subroutine kid_check(rc, h, what)
+    integer(c_int), intent(in) :: rc
+    type(c_ptr), intent(in) :: h
+    character(len=*), intent(in) :: what
+    if (rc /= KID_OK) then
+      write(0, '(a,a,a,i0,a,a)') 'KID, ', what, ': status ', rc, ' ', kid_last_error_f(h)
+      error stop 1
+    end if
+  end subroutine
+
+end module kid_hip_mod

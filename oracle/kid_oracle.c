@@ -1375,7 +1375,8 @@ static void sum_up_spread_field(const ko_grid *g, const double *acc, int base, i
     }
 #undef V
 }
-void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc, double *out) {
+/* calculate_mass_on_ocean (IB:4970-5011): the per-berg scatter half of create_gridded_icebergs_fields */
+void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
   for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
   int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)(b->n > 0 ? b->n : 1));
@@ -1420,6 +1421,12 @@ void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, ki
 #undef ACC
   }
   free(perm);
+}
+/* the per-cell half: sum_up_spread_fields (IB:6077-6150) + IB:3449-3488.  In a particle-sharded run this is what
+ * follows the all-reduce of the accumulators. */
+void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double *out) {
+  const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
+  const int dm = p->diag_mask;
   double *o_mass = out + (size_t)KID_O_SPREAD_MASS * ncell, *o_area = out + (size_t)KID_O_SPREAD_AREA * ncell;
   double *o_u = out + (size_t)KID_O_SPREAD_UVEL * ncell, *o_v = out + (size_t)KID_O_SPREAD_VVEL * ncell;
   double *o_us = out + (size_t)KID_O_USTAR_ICEBERG * ncell;
@@ -1468,6 +1475,21 @@ void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, ki
   }
 }
 
+void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc, double *out) {
+  ko_calculate_mass_on_ocean(g, p, b, acc);
+  ko_gather_fields(g, p, acc, out);
+}
+/* everything of one step that is per berg (the part a rank does on its own shard); accumulators zeroed first */
+void ko_step_local(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity, double *acc, double *scalars) {
+  const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
+  memset(acc, 0, (size_t)KID_NACC * ncell * sizeof(double));
+  if (!p->mts && !p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
+  if (!p->static_icebergs) ko_evolve_icebergs(g, p, b, scalars);
+  if (p->footloose) ko_footloose_calving(g, p, b, capacity, acc, scalars);
+  if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
+  ko_thermodynamics(g, p, b, acc, scalars);
+  ko_calculate_mass_on_ocean(g, p, b, acc);
+}
 /* one icebergs_run() worth of the hot path, IB:5423-5512 (non-MTS, non-interactive) */
 void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
                  double *acc, double *out, double *scalars) {

@@ -61,6 +61,9 @@ void ko_evolve_icebergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b, 
 void ko_thermodynamics(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc, double *scalars);
 void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, kid_berg_soa *b,
                                        double *acc, double *out);
+void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc);
+void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double *out);
+void ko_step_local(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity, double *acc, double *scalars);
 void ko_footloose_calving(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
                           double *acc, double *scalars);
 /* One icebergs_run() worth of the hot path (IB:5423-5512), accumulators zeroed first.

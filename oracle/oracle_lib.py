@@ -72,6 +72,10 @@ def load():
     lib.ko_create_gridded_icebergs_fields.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
     lib.ko_footloose_calving.restype = None
     lib.ko_footloose_calving.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64, C.POINTER(d), C.POINTER(d)]
+    lib.ko_step_local.restype = None
+    lib.ko_step_local.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64, C.POINTER(d), C.POINTER(d)]
+    lib.ko_gather_fields.restype = None
+    lib.ko_gather_fields.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(d), C.POINTER(d)]
     lib.ko_run_step.restype = None
     lib.ko_run_step.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64,
                                 C.POINTER(d), C.POINTER(d), C.POINTER(d)]
@@ -128,6 +132,13 @@ class Oracle:
             s.i32[k] = a.ctypes.data_as(C.POINTER(C.c_int32))
         s.id = bergs["id"].ctypes.data_as(C.POINTER(C.c_int64))
         return s
+
+    def step_local(self, bergs):
+        s = self.soa(bergs)
+        self.lib.ko_step_local(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]), _dp(self.acc), _dp(self.scalars))
+
+    def step_gather(self):
+        self.lib.ko_gather_fields(C.byref(self.kg), C.byref(self.params), _dp(self.acc), _dp(self.out))
 
     def run_step(self, bergs, nsteps=1):
         s = self.soa(bergs)

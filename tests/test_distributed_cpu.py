@@ -1,0 +1,88 @@
+"""The N>1 path on CPU: two gloo ranks shard a population by particle index, all-reduce the per-cell accumulators
+and gather; every rank must end with the single-process result.  The per-berg compute in these
+CPU tests is the oracle standing in for the GPU backend; what is under test is the sharding / reduction logic of
+icebergs_amd.distributed, which bench.py drives with the HIP backend."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleBackend:
+    def __init__(self, oracle, bergs):
+        self.o, self.b = oracle, bergs
+
+    def step_local(self):
+        self.o.step_local(self.b)
+
+    def step_gather(self):
+        self.o.step_gather()
+
+
+def _worker(rank, world, port, nbergs, nsteps, out_dir):
+    import oracle_lib
+    from icebergs_amd import synthetic as S, distributed as D, types as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grid, p, b = S.config_c2(n=nbergs, seed=17, continents=True)
+    mine = D.take_shard(b, rank, world)
+    o = oracle_lib.Oracle(grid, p)
+    ncell = o.ni * o.nj
+    # one contiguous block [planes | scalars], as the HIP handle lays it out
+    block = np.zeros(T.NACC * ncell + T.NSCALAR)
+    o.acc = block[: T.NACC * ncell].reshape(T.NACC, o.nj, o.ni)
+    o.scalars = block[T.NACC * ncell:]
+    stepper = D.ShardedStepper(OracleBackend(o, mine), torch.from_numpy(block), ncell, p.diag_mask, dist)
+    totals = np.zeros(T.NSCALAR)
+    for _ in range(nsteps):
+        o.scalars[:] = 0.0
+        stepper.step()
+        totals += o.scalars
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), acc=o.acc, out=o.out, totals=totals,
+             **{"b_" + k: v for k, v in mine.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    from icebergs_amd import distributed as D
+    for n in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_rank_gloo_matches_single_process(tmp_path, world):
+    import oracle_lib
+    import parity as P
+    from icebergs_amd import synthetic as S, types as T
+    oracle_lib.build()
+    nbergs, nsteps = 6000, 4
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, nbergs, nsteps, str(tmp_path)), nprocs=world, join=True)
+    grid, p, b = S.config_c2(n=nbergs, seed=17, continents=True)
+    rb, racc, rout, rscal = P.run_oracle(grid, p, b, nsteps)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):  # every rank holds the same reduced fields
+        for k in range(T.ENUMS["KID_NACC_CORE"]):
+            assert P.rel_err(parts[r]["acc"][k], racc[k]) <= P.TOL_GRID, (r, k)
+        for k in range(T.NOUT):
+            assert P.rel_err(parts[r]["out"][k], rout[k]) <= P.TOL_GRID, (r, k)
+        assert parts[r]["totals"][T.SCALAR_NAMES["nbergs_melted"]] == rscal[T.SCALAR_NAMES["nbergs_melted"]]
+    for name in P.TRAJ_FIELDS + P.SIZE_FIELDS:  # the shards, put back together, are the single-process population
+        got = np.concatenate([parts[r]["b_" + name] for r in range(world)])
+        assert np.array_equal(got, rb[name]), name

@@ -1,0 +1,104 @@
+"""The Fortran host path: the stand-alone Fortran driver (icebergs_amd/fortran/kid_replay.F90) drives the HIP library
+through the ISO_C_BINDING module exactly as icebergs_run would (same call sites), and must reproduce the oracle."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from icebergs_amd import synthetic as S
+from icebergs_amd import types as T
+import parity as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPLAY = os.path.join(ROOT, "icebergs_amd", "fortran", "kid_replay")
+MAGIC = 1263093761
+
+
+def write_case(path, grid, p, b, nsteps, mode):
+    n = len(b["lon"])
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", MAGIC))
+        f.write(bytes(grid["desc"]))
+        f.write(bytes(p))
+        f.write(struct.pack("<ii", nsteps, mode))
+        f.write(struct.pack("<q", n))
+        for name in T.GRID_STATIC_NAMES:
+            f.write(np.ascontiguousarray(grid["static"][name], dtype=np.float64).tobytes())
+        for name in T.FORCING_NAMES:
+            f.write(np.ascontiguousarray(grid["forcing"][name], dtype=np.float64).tobytes())
+        for name in T.BERG_F64_NAMES:
+            f.write(b[name].tobytes())
+        for name in T.BERG_I32_NAMES:
+            f.write(b[name].tobytes())
+        f.write(b["id"].tobytes())
+
+
+def read_result(path, grid):
+    d = grid["desc"]
+    ni, nj = d.ied - d.isd + 1, d.jed - d.jsd + 1
+    with open(path, "rb") as f:
+        n = struct.unpack("<q", f.read(8))[0]
+        b = {}
+        for name in T.BERG_F64_NAMES:
+            b[name] = np.frombuffer(f.read(8 * n), dtype=np.float64).copy()
+        for name in T.BERG_I32_NAMES:
+            b[name] = np.frombuffer(f.read(4 * n), dtype=np.int32).copy()
+        b["id"] = np.frombuffer(f.read(8 * n), dtype=np.int64).copy()
+        acc = np.frombuffer(f.read(8 * T.NACC * ni * nj), dtype=np.float64).reshape(T.NACC, nj, ni).copy()
+        out = np.frombuffer(f.read(8 * T.NOUT * ni * nj), dtype=np.float64).reshape(T.NOUT, nj, ni).copy()
+        scal = np.frombuffer(f.read(8 * T.NSCALAR), dtype=np.float64).copy()
+    return b, acc, out, scal
+
+
+def test_fortran_binding_matches_header():
+    """CPU check: the generated Fortran types are up to date with include/kid_types.h."""
+    inc = os.path.join(ROOT, "icebergs_amd", "fortran", "kid_types_gen.inc")
+    before = open(inc).read()
+    subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_fortran_types.py")], check=True, capture_output=True)
+    assert open(inc).read() == before, "run tools/gen_fortran_types.py and commit the result"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fortran_driver_config1(oracle, tmp_path, mode):
+    if not os.path.exists(REPLAY):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(REPLAY)], check=True)
+    grid, p, b = S.config_c1()
+    S.set_diag_all(p)
+    nsteps = 72
+    case, res = str(tmp_path / "case.bin"), str(tmp_path / "res.bin")
+    write_case(case, grid, p, b, nsteps, mode)
+    r = subprocess.run([REPLAY, case, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = read_result(res, grid)
+    ref = P.run_oracle(grid, p, b, nsteps)
+    P.compare(ref, got, "fortran/C1/mode%d" % mode)
+
+
+@pytest.mark.gpu
+def test_fortran_driver_config2(oracle, tmp_path):
+    if not os.path.exists(REPLAY):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(REPLAY)], check=True)
+    grid, p, b = S.config_c2(n=20000, seed=31, continents=True)
+    case, res = str(tmp_path / "case.bin"), str(tmp_path / "res.bin")
+    write_case(case, grid, p, b, 6, 0)
+    r = subprocess.run([REPLAY, case, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = read_result(res, grid)
+    ref = P.run_oracle(grid, p, b, 6)
+    P.compare(ref, got, "fortran/C2")
+
+
+@pytest.mark.gpu
+def test_fortran_driver_reports_errors(tmp_path):
+    """A bad request must abort with the library's message (the reference's FATAL convention), not continue."""
+    grid, p, b = S.config_c1()
+    p.mts = 1  # not implemented in this build -> KID_EUNSUPPORTED from kid_create
+    case, res = str(tmp_path / "case.bin"), str(tmp_path / "res.bin")
+    write_case(case, grid, p, b, 1, 0)
+    r = subprocess.run([REPLAY, case, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "mts/dem" in (r.stderr + r.stdout)

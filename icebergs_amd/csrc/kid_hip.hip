@@ -338,6 +338,20 @@ __global__ void __launch_bounds__(256) alive_to_u32_kernel(const int32_t *alive,
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
   if (k < n) flag[k] = alive[k] ? 1u : 0u;
 }
+// cell key of every berg (dead bergs sort to the end) + identity permutation, for kid_move_berg_between_cells
+__global__ void __launch_bounds__(256) cell_key_kernel(const int32_t *ine, const int32_t *jne, const int32_t *alive, int isd, int jsd, int ni,
+                                                       unsigned dead_key, unsigned *key, unsigned *idx, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n) {
+    key[k] = alive[k] ? (unsigned)((ine[k] - isd) + (jne[k] - jsd) * ni) : dead_key;
+    idx[k] = (unsigned)k;
+  }
+}
+template <typename TT>
+__global__ void __launch_bounds__(256) permute_kernel(const TT *src, TT *dst, const unsigned *perm, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n) dst[k] = src[perm[k]];
+}
 __global__ void __launch_bounds__(256) fill_i32_kernel(int32_t *p, int32_t v, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
   if (k < n) p[k] = v;
@@ -369,6 +383,10 @@ struct kid_handle {
   double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
   unsigned long long *d_count = nullptr;
   int *d_redo_list = nullptr, *d_redo_count = nullptr;  // bergs the FAST build hands to the general build
+  unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
+  void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  double *d_perm_spare = nullptr;
+  int resort_interval = 16, steps_since_sort = 0;
   Flags flags{0, 0, 1, 0};
   bool have_static = false, have_forcing = false;
   bool profile = false;
@@ -494,6 +512,9 @@ int kid_destroy(kid_handle *h) {
   if (h->d_count) (void)hipFree(h->d_count);
   if (h->d_bp) (void)hipFree(h->d_bp);
   if (h->d_params) (void)hipFree(h->d_params);
+  for (int q = 0; q < 2; ++q) { if (h->d_key[q]) (void)hipFree(h->d_key[q]); if (h->d_idx[q]) (void)hipFree(h->d_idx[q]); }
+  if (h->d_sort_tmp) (void)hipFree(h->d_sort_tmp);
+  if (h->d_perm_spare) (void)hipFree(h->d_perm_spare);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
   if (h->d_redo_count) (void)hipFree(h->d_redo_count);
   for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
@@ -706,6 +727,64 @@ int kid_compact_bergs(kid_handle *h) {
   return KID_OK;
 }
 
+// move_berg_between_cells (IB:5437, FW:1758-1797): re-bin the bergs after they moved.  With per-cell linked lists
+// that is list surgery; on the SoA it is a stable device radix sort by cell index (j-major, i-minor: the reference's
+// traversal order, IB:7106) followed by a gather of every field.  Dead bergs sort to the end and are dropped.
+// Correctness never depends on it (the kernels accept any order); speed does: the hot build shares LDS cell
+// packets and atomics between the lanes of a wave that sit in the same cell.
+int kid_move_berg_between_cells(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  h->steps_since_sort = 0;
+  if (h->n == 0) return KID_OK;
+  const long long n = h->n;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (!h->d_key[0]) {
+    for (int q = 0; q < 2; ++q) {
+      KID_HIP(h, hipMalloc(&h->d_key[q], (size_t)h->capacity * sizeof(unsigned)));
+      KID_HIP(h, hipMalloc(&h->d_idx[q], (size_t)h->capacity * sizeof(unsigned)));
+    }
+    KID_HIP(h, hipMalloc(&h->d_perm_spare, (size_t)h->capacity * sizeof(double)));
+    size_t tmp = 0;
+    KID_HIP(h, rocprim::radix_sort_pairs(nullptr, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)h->capacity, 0u, 32u, h->stream));
+    h->sort_tmp_bytes = tmp;
+    KID_HIP(h, hipMalloc(&h->d_sort_tmp, tmp));
+  }
+  const unsigned dead_key = (unsigned)h->ncell;  // larger than any cell index
+  unsigned bits = 1; while ((1ull << bits) <= (unsigned long long)dead_key) ++bits;
+  hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], h->bp.i[KID_BI_ALIVE],
+                     h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_idx[0], n);
+  size_t tmp = h->sort_tmp_bytes;
+  KID_HIP(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)n, 0u, bits, h->stream));
+  int64_t n_alive = 0;
+  int rc = kid_num_bergs(h, nullptr, &n_alive);
+  if (rc) return rc;
+  const unsigned *perm = h->d_idx[1];
+  for (int f = 0; f < KID_NB_F64; ++f) {
+    hipLaunchKernelGGL(permute_kernel<double>, dim3(nb), dim3(256), 0, h->stream, h->bp.f[f], h->d_perm_spare, perm, n);
+    std::swap(h->bp.f[f], h->d_perm_spare);
+  }
+  {
+    int64_t *spare = (int64_t *)h->d_perm_spare;
+    hipLaunchKernelGGL(permute_kernel<int64_t>, dim3(nb), dim3(256), 0, h->stream, h->bp.id, spare, perm, n);
+    double *old = (double *)h->bp.id; h->bp.id = spare; h->d_perm_spare = old;
+  }
+  for (int f = 0; f < KID_NB_I32; ++f) {
+    int32_t *spare = (int32_t *)h->d_key[0];  // keys are no longer needed: reuse as the int32 spare
+    hipLaunchKernelGGL(permute_kernel<int32_t>, dim3(nb), dim3(256), 0, h->stream, h->bp.i[f], spare, perm, n);
+    unsigned *old = (unsigned *)h->bp.i[f]; h->bp.i[f] = spare; h->d_key[0] = old;
+  }
+  KID_HIP(h, hipGetLastError());
+  h->n = n_alive;  // the dead sorted to the tail
+  h->tables_dirty = true;
+  return KID_OK;
+}
+int kid_set_resort_interval(kid_handle *h, int steps) {
+  if (!h || steps < 0) return KID_EINVAL;
+  h->resort_interval = steps;
+  return KID_OK;
+}
+
 int kid_zero_accumulators(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
@@ -799,7 +878,6 @@ int kid_create_gridded_icebergs_fields(kid_handle *h) {
 int kid_step_local(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
-  if (h->profile) KID_HIP(h, hipEventRecord(h->ev2, h->stream));
   int rc = kid_zero_accumulators(h);
   if (rc) return rc;
   const kid_params &p = h->params;
@@ -820,19 +898,6 @@ int kid_step_gather(kid_handle *h) {
   KID_HIP(h, hipSetDevice(h->device));
   int rc = launch_gather(h);
   if (rc) return rc;
-  if (h->profile) {
-    KID_HIP(h, hipEventRecord(h->ev3, h->stream));
-    KID_HIP(h, hipEventSynchronize(h->ev3));
-    float ms = 0.f;
-    KID_HIP(h, hipEventElapsedTime(&ms, h->ev2, h->ev3));
-    h->all_ms += ms;
-    for (auto &pe : h->pending) {
-      KID_HIP(h, hipEventElapsedTime(&ms, pe.first, pe.second));
-      h->berg_ms += ms;
-      (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second);
-    }
-    h->pending.clear();
-  }
   return KID_OK;
 }
 int kid_run_step(kid_handle *h, int nsteps) {
@@ -842,6 +907,10 @@ int kid_run_step(kid_handle *h, int nsteps) {
     if (rc) return rc;
     rc = kid_step_gather(h);
     if (rc) return rc;
+    if (h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised
+      rc = kid_move_berg_between_cells(h);
+      if (rc) return rc;
+    }
   }
   return KID_OK;
 }
@@ -883,6 +952,16 @@ int kid_profile_enable(kid_handle *h, int on) {
 }
 int kid_profile_get(kid_handle *h, double *berg_ms, int64_t *launches, double *all_ms) {
   if (!h) return KID_EINVAL;
+  // the events were only recorded while stepping (no host/device sync in the timed loop); resolve them now
+  KID_HIP(h, hipSetDevice(h->device));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  for (auto &pe : h->pending) {
+    float ms = 0.f;
+    KID_HIP(h, hipEventElapsedTime(&ms, pe.first, pe.second));
+    h->berg_ms += ms;
+    (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second);
+  }
+  h->pending.clear();
   if (berg_ms) *berg_ms = h->berg_ms;
   if (launches) *launches = h->berg_launches;
   if (all_ms) *all_ms = h->all_ms;

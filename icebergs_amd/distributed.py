@@ -41,8 +41,10 @@ class ShardedStepper:
     `backend` is anything with step_local() / step_gather() that accumulates into `acc_block` (a torch tensor:
     device memory bound to the HIP handle in production, host memory in the gloo tests)."""
 
-    def __init__(self, backend, acc_block, ncell, diag_mask=0, dist=None):
+    def __init__(self, backend, acc_block, ncell, diag_mask=0, dist=None, resort_interval=16):
         self.backend = backend
+        self.resort_interval = resort_interval
+        self._since_sort = 0
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.planes, self.scalars = accumulator_views(acc_block, ncell, diag_mask)
 
@@ -52,3 +54,7 @@ class ShardedStepper:
             self.dist.all_reduce(self.planes)
             self.dist.all_reduce(self.scalars)
         self.backend.step_gather()
+        self._since_sort += 1
+        if self.resort_interval and self._since_sort >= self.resort_interval and hasattr(self.backend, "move_berg_between_cells"):
+            self.backend.move_berg_between_cells()  # icebergs.F90:5437, amortised over `resort_interval` steps
+            self._since_sort = 0

@@ -120,6 +120,13 @@ class Icebergs:
         self._check(self.lib.kid_download_bergs(self.h, C.byref(s)), "kid_download_bergs")
         return b
 
+    def move_berg_between_cells(self):
+        """IB:5437: re-bin (stable sort by cell, dead bergs dropped)."""
+        self._check(self.lib.kid_move_berg_between_cells(self.h), "kid_move_berg_between_cells")
+
+    def set_resort_interval(self, steps):
+        self._check(self.lib.kid_set_resort_interval(self.h, int(steps)), "kid_set_resort_interval")
+
     def compact(self):
         self._check(self.lib.kid_compact_bergs(self.h), "kid_compact_bergs")
 

@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("KID_HIP_SO", os.path.join(_CSRC, "libkid_hip.so"))  # 
 SYMBOLS = [
     "kid_create", "kid_destroy", "kid_set_params", "kid_set_stream", "kid_sync", "kid_last_error", "kid_version",
     "kid_sizeof", "kid_set_static_grid", "kid_set_forcing", "kid_set_forcing_device", "kid_upload_bergs", "kid_download_bergs",
-    "kid_num_bergs", "kid_compact_bergs", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
+    "kid_num_bergs", "kid_compact_bergs", "kid_move_berg_between_cells", "kid_set_resort_interval", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
     "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
     "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
     "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
@@ -61,7 +61,8 @@ def load():
     lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_download_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_num_bergs.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    for name in ("kid_compact_bergs", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
+    lib.kid_set_resort_interval.argtypes = [H, C.c_int]
+    for name in ("kid_compact_bergs", "kid_move_berg_between_cells", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
                  "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics",
                  "kid_create_gridded_icebergs_fields", "kid_step_local", "kid_step_gather"):
         getattr(lib, name).argtypes = [H]

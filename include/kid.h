@@ -13,6 +13,7 @@
  *   accumulator zeroing                   IB:5125-5156     kid_zero_accumulators
  *   interp_gridded_fields_to_bergs        IB:5423, 5473    kid_interp_gridded_fields_to_bergs
  *   evolve_icebergs                       IB:5433          kid_evolve_icebergs
+ *   move_berg_between_cells               IB:5437          kid_move_berg_between_cells
  *   footloose_calving                     IB:5453          kid_footloose_calving
  *   thermodynamics                        IB:5505          kid_thermodynamics
  *   create_gridded_icebergs_fields        IB:5512          kid_create_gridded_icebergs_fields
@@ -68,6 +69,10 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host);        /* sets th
 int kid_download_bergs(kid_handle *h, kid_berg_soa *host);            /* host->n must be >= kid_num_bergs slots */
 int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive); /* slots include dead bergs until compaction */
 int kid_compact_bergs(kid_handle *h);                                 /* drop melted / departed bergs, keep order */
+/* move_berg_between_cells (IB:5437): stable device sort of the SoA by cell (j-major), dead bergs dropped.  Results
+ * never depend on it, speed does.  kid_run_step calls it every `steps` steps (default 16; 0 = never). */
+int kid_move_berg_between_cells(kid_handle *h);
+int kid_set_resort_interval(kid_handle *h, int steps);
 
 /* ---- the hot path, phase by phase (same order as icebergs_run, IB:5423-5512) ---- */
 int kid_zero_accumulators(kid_handle *h);

@@ -68,7 +68,7 @@ def test_c2_phases_equals_fused(oracle):
     a = P.run_hip(grid, p, b, 5, mode="fused")
     c = P.run_hip(grid, p, b, 5, mode="phases")
     for f in P.TRAJ_FIELDS + P.SIZE_FIELDS:
-        assert np.array_equal(a[0][f], c[0][f]), f  # same device arithmetic -> bitwise equal state
+        assert np.array_equal(a[0][f], c[0][f]), f  # same device arithmetic -> bitwise equal state (5 steps: no re-binning yet)
     for k in range(a[1].shape[0]):
         assert P.rel_err(a[1][k], c[1][k]) <= 1e-12
 
@@ -100,6 +100,7 @@ def test_melting_to_death_and_compaction(oracle):
     P.compare(ref, got, "melt-to-death")
     assert ref[3][1] > 0, "the test must actually melt some bergs"
     ib = Icebergs(grid, p, capacity=len(b["lon"]))
+    ib.set_resort_interval(0)
     ib.upload_bergs(b)
     ib.run(10)
     slots, alive = ib.num_bergs()
@@ -107,8 +108,8 @@ def test_melting_to_death_and_compaction(oracle):
     slots2, alive2 = ib.num_bergs()
     assert slots2 == alive == alive2 < slots
     cb = ib.download_bergs()
-    keep = got[0]["alive"] != 0
-    assert np.array_equal(cb["id"], got[0]["id"][keep])
+    keep = got[0]["alive"] != 0  # run_hip did 10 steps: below the default re-binning interval, order untouched
+    assert np.array_equal(cb["id"], got[0]["id"][keep])  # compaction keeps the order
     assert np.array_equal(cb["lon"], got[0]["lon"][keep])
     ib.close()
 
@@ -136,3 +137,37 @@ def test_hexagonal_spreading(oracle):
     p.initial_orientation = 10.0
     ref, got = _both(grid, p, b, 3, "fused")
     P.compare(ref, got, "hexagonal")
+
+
+def test_move_berg_between_cells(oracle):
+    """Re-binning (IB:5437) is a stable sort by cell that drops dead bergs; results do not depend on how often it runs."""
+    from icebergs_amd.framework import Icebergs
+    grid, p, b = S.config_c2(n=30000, seed=13, continents=True)
+    rng = np.random.default_rng(0)
+    shuffle = rng.permutation(len(b["lon"]))          # start from a completely unsorted population
+    b = {k: np.ascontiguousarray(v[shuffle]) for k, v in b.items()}
+    b["alive"][::97] = 0                                # and some bergs that are already gone
+    ref = P.run_oracle(grid, p, b, 6)
+    res = []
+    for interval in (0, 1, 4):
+        ib = Icebergs(grid, p, capacity=len(b["lon"]))
+        ib.set_resort_interval(interval)
+        ib.upload_bergs(b)
+        ib.run(6)
+        acc, out, scal = ib.fetch()
+        got = (ib.download_bergs(), acc.copy(), out.copy(), scal.copy())
+        P.compare(ref, got, "resort interval %d" % interval)
+        res.append(got)
+        if interval == 1:
+            gb = got[0]
+            d = grid["desc"]
+            key = (gb["jne"].astype(np.int64) - d.jsd) * (d.ied - d.isd + 1) + (gb["ine"] - d.isd)
+            assert gb["alive"].all() and len(gb["lon"]) == int(ref[0]["alive"].sum())
+            # sorted by the cell the bergs were in when the last re-binning ran (the last step moved a few on)
+            assert np.mean(np.diff(key) >= 0) > 0.97
+        ib.close()
+    order = [np.argsort(r[0]["id"][r[0]["alive"] != 0]) for r in res]
+    for f in P.TRAJ_FIELDS + P.SIZE_FIELDS:
+        base = res[0][0][f][res[0][0]["alive"] != 0][order[0]]
+        for r, o in zip(res[1:], order[1:]):
+            assert np.array_equal(base, r[0][f][r[0]["alive"] != 0][o]), f

@@ -13,6 +13,7 @@
 //                                the reference's phase-by-phase call sites and the fused per-step launch share
 //                                one body.  HBM-streaming on the SoA, grid served from L2 / Infinity Cache.
 //   gather_kernel              : per cell, the 9-point gather of sum_up_spread_fields (IB:6126-6138) + ustar.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string.h>
@@ -317,10 +318,14 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
 }
 
 __global__ void __launch_bounds__(256) count_alive_kernel(const int32_t *alive, long long n, unsigned long long *out) {
-  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
-  const bool a = (k < n) && alive[k] != 0;
-  const unsigned long long m = __ballot(a);
-  if (__lane_id() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+  __shared__ unsigned wsum[4];
+  unsigned local = 0;
+  for (long long k = (long long)blockIdx.x * 256ll + threadIdx.x; k < n; k += (long long)gridDim.x * 256ll) local += alive[k] ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
 }
 __global__ void __launch_bounds__(256) compact_f64_kernel(const double *src, double *dst, const int32_t *alive, const unsigned *pos, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
@@ -675,7 +680,7 @@ int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
   if (n_alive) {
     unsigned long long cnt = 0;
     KID_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(cnt), h->stream));
-    if (h->n > 0) hipLaunchKernelGGL(count_alive_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], (long long)h->n, h->d_count);
+    if (h->n > 0) hipLaunchKernelGGL(count_alive_kernel, dim3((unsigned)std::min<long long>((h->n + 255) / 256, 1024)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], (long long)h->n, h->d_count);
     KID_HIP(h, hipMemcpyAsync(&cnt, h->d_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
     KID_HIP(h, hipStreamSynchronize(h->stream));
     *n_alive = (int64_t)cnt;

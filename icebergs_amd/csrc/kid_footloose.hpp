@@ -1,0 +1,146 @@
+// kid_footloose.hpp -- footloose calving on the SoA (gfx950), one lane per berg.
+//   footloose_calving  IB:2503-2734      calve_fl_icebergs  IB:6405-6569      generate_id  FW:4165-4179
+// A calving event is rare (a parent sheds a child every few hundred steps), so this is a short streaming kernel
+// between the evolve and the thermodynamics launches.  New bergs are appended behind the population through an
+// atomic cursor; their ids come from the per-cell counter of the parent's cell (atomic, so ids are unique; when
+// two bergs of one cell calve in the same step the reference hands the counter values out in list order, here
+// the order is the atomics').  Only displace_fl_bergs=.false. exists: the displaced variant draws from FMS's
+// random stream.  The "new berg from FL bits" branch uses l_b of the berg at hand (the reference reuses the
+// local left by the previous berg of the loop, IB:2667).
+#pragma once
+#include "kid_device.hpp"
+#include "kid_thermo.hpp"
+
+namespace kid {
+
+struct FlChildCtx {
+  int *cursor;          // number of children appended in this launch
+  int32_t *counter;     // grd%iceberg_counter_grd
+  long long n, capacity;
+  int iNg;              // zonal size of the global grid (ij_component_of_id, FW:4227-4240)
+};
+
+// calve_fl_icebergs with displace=.false.; returns false if the SoA is full
+template <class BP>
+__device__ __forceinline__ bool calve_child(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long pk,
+                                            double k, double l_b, bool from_bits) {
+  const int slot = atomicAdd(cx.cursor, 1);
+  const long long c = cx.n + slot;
+  if (c >= cx.capacity) return false;
+#pragma unroll 1
+  for (int f = 0; f < KID_NB_F64; ++f) b.f[f][c] = 0.0;
+  b.f[KID_B_LON][c] = b.f[KID_B_LON][pk]; b.f[KID_B_LAT][c] = b.f[KID_B_LAT][pk];
+  b.f[KID_B_XI][c] = b.f[KID_B_XI][pk]; b.f[KID_B_YJ][c] = b.f[KID_B_YJ][pk];
+  const int pi = b.i[KID_BI_INE][pk], pj = b.i[KID_BI_JNE][pk];
+  b.i[KID_BI_INE][c] = pi; b.i[KID_BI_JNE][c] = pj;
+  const double pms = b.f[KID_B_MASS_SCALING][pk];
+  if (from_bits) {  // IB:6488-6497
+    double Lfl, Wfl, Tfl;
+    fl_bits_dimensions(p, b.f[KID_B_THICKNESS][pk], Lfl, Wfl, Tfl);
+    const double cmass = Tfl * Lfl * Wfl * p.rho_bergs;
+    const double cms = k * p.new_berg_from_fl_bits_mass_thres / cmass;
+    b.f[KID_B_LENGTH][c] = Lfl; b.f[KID_B_WIDTH][c] = Wfl; b.f[KID_B_THICKNESS][c] = Tfl;
+    b.f[KID_B_MASS][c] = cmass; b.f[KID_B_MASS_SCALING][c] = cms;
+    const double percent_fl = (cmass * cms) / (b.f[KID_B_MASS_OF_FL_BITS][pk] * pms);
+    b.f[KID_B_MASS_OF_BITS][c] = (percent_fl * b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk] * pms) / cms;
+    b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk] = (1 - percent_fl) * b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk];
+    b.f[KID_B_MASS_OF_FL_BITS][pk] = b.f[KID_B_MASS_OF_FL_BITS][pk] - k * p.new_berg_from_fl_bits_mass_thres / pms;
+  } else {          // IB:6499-6504
+    const double len = l_b * 3., wid = l_b, thick = b.f[KID_B_THICKNESS][pk];
+    b.f[KID_B_LENGTH][c] = len; b.f[KID_B_WIDTH][c] = wid; b.f[KID_B_THICKNESS][c] = thick;
+    b.f[KID_B_MASS][c] = wid * len * thick * p.rho_bergs;
+    b.f[KID_B_MASS_SCALING][c] = pms * k;
+    b.f[KID_B_MASS_OF_BITS][c] = 0.0;
+  }
+  b.f[KID_B_START_LON][c] = b.f[KID_B_LON][c]; b.f[KID_B_START_LAT][c] = b.f[KID_B_LAT][c];
+  b.f[KID_B_LON_OLD][c] = b.f[KID_B_LON_OLD][pk] + 0.0; b.f[KID_B_LAT_OLD][c] = b.f[KID_B_LAT_OLD][pk] + 0.0;
+  b.f[KID_B_START_DAY][c] = p.current_yearday;
+  b.f[KID_B_MASS_OF_FL_BITS][c] = 0.0; b.f[KID_B_MASS_OF_FL_BERGY_BITS][c] = 0.0;
+  b.f[KID_B_FL_K][c] = -1.0;
+  b.i[KID_BI_START_YEAR][c] = p.current_year;
+  {  // generate_id FW:4165-4179 at the parent's cell
+    const int32_t cnt = atomicAdd(cx.counter + g.idx(pi, pj), 1) + 1;
+    const int32_t ij = pi + (cx.iNg * (pj - 1));
+    b.id[c] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)ij;
+  }
+  b.f[KID_B_HALO_BERG][c] = 0.0;
+  const int same[] = {KID_B_START_MASS, KID_B_UVEL, KID_B_VVEL, KID_B_AXN, KID_B_AYN, KID_B_BXN, KID_B_BYN,
+                      KID_B_UVEL_PREV, KID_B_VVEL_PREV, KID_B_UVEL_OLD, KID_B_VVEL_OLD, KID_B_HEAT_DENSITY,
+                      KID_B_STATIC_BERG, KID_B_UO, KID_B_VO, KID_B_UI, KID_B_VI, KID_B_UA, KID_B_VA, KID_B_SSH_X,
+                      KID_B_SSH_Y, KID_B_SST, KID_B_SSS, KID_B_CN, KID_B_HI, KID_B_OD};
+#pragma unroll 1
+  for (unsigned q = 0; q < sizeof(same) / sizeof(same[0]); ++q) b.f[same[q]][c] = b.f[same[q]][pk];
+  b.i[KID_BI_N_BONDS][c] = 0;
+  b.i[KID_BI_ALIVE][c] = 1;
+  return true;
+}
+
+template <class BP>
+__device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long q,
+                                              double *acc, size_t ncell, double *scal) {
+  const int i = b.i[KID_BI_INE][q], j = b.i[KID_BI_JNE][q];
+  if (i < g.isc || i > g.iec || j < g.jsc || j > g.jec) return;  // computational domain only, IB:2554
+  const int c = g.idx(i, j);
+  const double area = g.geo[c].area, ms = b.f[KID_B_MASS_SCALING][q];
+  // constants IB:2538-2547
+  const double e1 = exp(0.25 * p.pi), drho = RHO_SEAWATER - p.rho_bergs, sigmay = p.fl_strength * 1000;
+  const double lfootparam = e1 * RHO_SEAWATER * sigmay / (6 * p.rho_bergs * GRAVITY * drho);
+  const double l_c = p.pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = p.fl_youngs / (12. * (1. - kid_pow(0.3, 2.)));
+  double T = b.f[KID_B_THICKNESS][q];
+  const double l_w = kid_pow(lw_c * B_c * kid_pow(T, 3.), 0.25);
+  const double l_b = l_c * l_w;
+  double nerr = 0., ncalved = 0.;
+  if (!(b.f[KID_B_STATIC_BERG][q] == 1 || b.f[KID_B_FL_K][q] < 0)) {
+    const double W = b.f[KID_B_WIDTH][q], L = b.f[KID_B_LENGTH][q];
+    const double l_b3 = 3 * l_b;
+    double cc = ceil((L - l_b3) / l_b3); const double Lmin = L - cc * l_b3;
+    cc = ceil((W - l_b3) / l_b3); const double Wmin = W - cc * l_b3;
+    const double max_k = dmax(floor((L * W - Lmin * Wmin) / (l_b3 * l_b)), 0);
+    double k = 0;
+    if (max_k != 0) {
+      const double foot_l = lfootparam * T / l_w;
+      const double foot_area = foot_l * l_b3;
+      const double flk = b.f[KID_B_FL_K][q];
+      k = floor(flk / foot_area);
+      if (k > max_k) k = max_k;
+      b.f[KID_B_FL_K][q] = flk - k * foot_area;
+    }
+    if (k > 0) {
+      double ds, Ln, Wn;
+      if (cc > 0) {
+        ds = 0.5 * ((L + W) - sqrt(kid_pow(L + W, 2.) - 4. * (l_b3 * l_b * k)));
+        Ln = L - ds; Wn = W - ds;
+        if (Wn < Wmin) { Ln = Ln * (1 - (Wmin - Wn) / Wmin); Wn = Wmin; }
+      } else {
+        ds = k * 3. * kid_pow(l_b, 2.) / W;
+        Ln = L - ds; Wn = W;
+      }
+      const double dA = L * W - Ln * Wn;
+      if (p.fl_style == KID_FL_STYLE_NEW_BERGS) {
+        if (!calve_child(g, p, b, cx, q, k, l_b, false)) nerr += 1.;
+        ncalved += 1.;
+      } else {
+        const double dM_fl_bits = p.rho_bergs * T * dA;
+        b.f[KID_B_MASS_OF_FL_BITS][q] = b.f[KID_B_MASS_OF_FL_BITS][q] + dM_fl_bits;
+        if (area != 0.) unsafeAtomicAdd(acc + (size_t)KID_A_FL_BITS_SRC * ncell + c, dM_fl_bits / (p.dt * area) * ms);
+      }
+      if (Ln <= 0 || Wn <= 0) nerr += 1.;  // FATAL IB:2649
+      else {
+        if (p.allow_bergs_to_roll) rolling(p, T, Wn, Ln);
+        b.f[KID_B_THICKNESS][q] = T; b.f[KID_B_WIDTH][q] = Wn; b.f[KID_B_LENGTH][q] = Ln;
+        b.f[KID_B_MASS][q] = Ln * Wn * T * p.rho_bergs;
+      }
+    }
+  }
+  const double bits = b.f[KID_B_MASS_OF_FL_BITS][q];
+  if (bits * ms > p.new_berg_from_fl_bits_mass_thres) {  // IB:2663-2673
+    const double k = floor(bits * ms / p.new_berg_from_fl_bits_mass_thres);
+    if (!calve_child(g, p, b, cx, q, k, l_b, true)) nerr += 1.;
+    ncalved += 1.;
+    if (area != 0.) unsafeAtomicAdd(acc + (size_t)KID_A_FL_BITS_SRC * ncell + c, -(k * p.new_berg_from_fl_bits_mass_thres / (p.dt * area)));
+  }
+  if (ncalved != 0.) unsafeAtomicAdd(scal + KID_S_NBERGS_CALVED_FL, ncalved);
+  if (nerr != 0.) unsafeAtomicAdd(scal + KID_S_ERROR_COUNT, nerr);
+}
+
+}  // namespace kid

@@ -24,6 +24,7 @@
 #include "../../include/kid.h"
 #include "kid_device.hpp"
 #include "kid_thermo.hpp"
+#include "kid_footloose.hpp"
 
 using namespace kid;
 
@@ -260,6 +261,16 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
   }  // grid-stride loop
 }
 
+// footloose_calving (IB:2503-2734): streaming pass, one lane per berg that existed when the pass started
+__global__ void __launch_bounds__(256) footloose_kernel(const DevGrid g, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt,
+                                                        const FlChildCtx cx, double *__restrict__ acc, const size_t ncell) {
+  const long long q = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (q >= cx.n) return;
+  const BergPtrs &b = *bt;
+  if (b.i[KID_BI_ALIVE][q] == 0) return;
+  footloose_one(g, *pp, b, cx, q, acc, ncell, acc + (size_t)KID_NACC * ncell);
+}
+
 // -------------------------------------------------------------------------------------------------------
 // IB:6077-6150 sum_up_spread_fields + IB:3449-3488, per cell of the computational domain
 // -------------------------------------------------------------------------------------------------------
@@ -388,6 +399,8 @@ struct kid_handle {
   double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
   unsigned long long *d_count = nullptr;
   int *d_redo_list = nullptr, *d_redo_count = nullptr;  // bergs the FAST build hands to the general build
+  int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
+  int *d_fl_cursor = nullptr;
   unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
   void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_perm_spare = nullptr;
@@ -488,6 +501,9 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_bp, sizeof(BergPtrs)));
   KID_HIP(h, hipMalloc(&h->d_params, sizeof(kid_params)));
   KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
+  KID_HIP(h, hipMalloc(&h->d_iceberg_counter, h->ncell * sizeof(int32_t)));
+  KID_HIP(h, hipMemset(h->d_iceberg_counter, 0, h->ncell * sizeof(int32_t)));
+  KID_HIP(h, hipMalloc(&h->d_fl_cursor, sizeof(int)));
   KID_HIP(h, hipMalloc(&h->d_redo_list, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipMalloc(&h->d_redo_count, sizeof(int)));
   KID_HIP(h, hipEventCreate(&h->ev0)); KID_HIP(h, hipEventCreate(&h->ev1));
@@ -520,6 +536,8 @@ int kid_destroy(kid_handle *h) {
   for (int q = 0; q < 2; ++q) { if (h->d_key[q]) (void)hipFree(h->d_key[q]); if (h->d_idx[q]) (void)hipFree(h->d_idx[q]); }
   if (h->d_sort_tmp) (void)hipFree(h->d_sort_tmp);
   if (h->d_perm_spare) (void)hipFree(h->d_perm_spare);
+  if (h->d_iceberg_counter) (void)hipFree(h->d_iceberg_counter);
+  if (h->d_fl_cursor) (void)hipFree(h->d_fl_cursor);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
   if (h->d_redo_count) (void)hipFree(h->d_redo_count);
   for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
@@ -802,6 +820,7 @@ int kid_zero_accumulators(kid_handle *h) {
 
 }  // extern "C"
 
+static int refresh_tables(kid_handle *h);
 template <unsigned PH>
 static int launch_berg(kid_handle *h) {
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
@@ -814,12 +833,7 @@ static int launch_berg(kid_handle *h) {
     KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1));
     KID_HIP(h, hipEventRecord(e0, h->stream));
   }
-if (h->tables_dirty) {  // refresh the device-side tables (pageable host source: effectively synchronous)
-    KID_HIP(h, hipMemcpyAsync(h->d_bp, &h->bp, sizeof(BergPtrs), hipMemcpyHostToDevice, h->stream));
-    KID_HIP(h, hipMemcpyAsync(h->d_params, &h->params, sizeof(kid_params), hipMemcpyHostToDevice, h->stream));
-    KID_HIP(h, hipStreamSynchronize(h->stream));
-    h->tables_dirty = false;
-  }
+{ int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
   const Redo redo{h->d_redo_list, h->d_redo_count};
   KID_HIP(h, hipMemsetAsync(h->d_redo_count, 0, sizeof(int), h->stream));
   // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
@@ -857,11 +871,50 @@ int kid_thermodynamics(kid_handle *h) {
   KID_HIP(h, hipMemsetAsync(h->d_acc + (size_t)KID_A_UVEL_ON_OCEAN * h->ncell, 0, 18 * h->ncell * sizeof(double), h->stream));
   return launch_berg<PH_THERMO>(h);
 }
+static int refresh_tables(kid_handle *h) {
+  if (h->tables_dirty) {  // refresh the device-side tables (pageable host source: effectively synchronous)
+    KID_HIP(h, hipMemcpyAsync(h->d_bp, &h->bp, sizeof(BergPtrs), hipMemcpyHostToDevice, h->stream));
+    KID_HIP(h, hipMemcpyAsync(h->d_params, &h->params, sizeof(kid_params), hipMemcpyHostToDevice, h->stream));
+    KID_HIP(h, hipStreamSynchronize(h->stream));
+    h->tables_dirty = false;
+  }
+  return KID_OK;
+}
 int kid_footloose_calving(kid_handle *h) {
   if (!h) return KID_EINVAL;
-  if (!h->params.footloose) return KID_OK;
-  h->err = "footloose_calving kernel is not built yet";
-  return KID_EUNSUPPORTED;
+  if (!h->params.footloose || h->n == 0) return KID_OK;
+  KID_HIP(h, hipSetDevice(h->device));
+  int rc = refresh_tables(h);
+  if (rc) return rc;
+  h->flags.has_fl = 1;
+  KID_HIP(h, hipMemsetAsync(h->d_fl_cursor, 0, sizeof(int), h->stream));
+  FlChildCtx cx{h->d_fl_cursor, h->d_iceberg_counter, (long long)h->n, (long long)h->capacity, h->gd.iec - h->gd.isc + 1};
+  hipLaunchKernelGGL(footloose_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), h->d_params, h->d_bp, cx, h->d_acc, h->ncell);
+  KID_HIP(h, hipGetLastError());
+  int appended = 0;  // the population grew: the host needs the new size before the next launch
+  KID_HIP(h, hipMemcpyAsync(&appended, h->d_fl_cursor, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  const int64_t room = h->capacity - h->n;
+  if (appended > room) {
+    h->n = h->capacity;
+    h->err = "footloose calving ran out of capacity: create the handle with room for child bergs";
+    return KID_ECAPACITY;
+  }
+  h->n += appended;
+  return KID_OK;
+}
+int kid_set_iceberg_counter(kid_handle *h, const int32_t *counter) {  // grd%iceberg_counter_grd, (isd:ied,jsd:jed)
+  if (!h || !counter) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  KID_HIP(h, hipMemcpy(h->d_iceberg_counter, counter, h->ncell * sizeof(int32_t), hipMemcpyHostToDevice));
+  return KID_OK;
+}
+int kid_get_iceberg_counter(kid_handle *h, int32_t *counter) {
+  if (!h || !counter) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  KID_HIP(h, hipMemcpy(counter, h->d_iceberg_counter, h->ncell * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return KID_OK;
 }
 
 static int launch_gather(kid_handle *h) {
@@ -886,7 +939,13 @@ int kid_step_local(kid_handle *h) {
   int rc = kid_zero_accumulators(h);
   if (rc) return rc;
   const kid_params &p = h->params;
-  if (p.footloose) { h->err = "fused step with footloose is not built yet"; return KID_EUNSUPPORTED; }
+  if (p.footloose) {  // calving sits between evolve and thermodynamics (IB:5453) and appends bergs: three launches
+    rc = launch_berg<PH_INTERP | PH_EVOLVE>(h);
+    if (rc) return rc;
+    rc = kid_footloose_calving(h);
+    if (rc) return rc;
+    return launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
+  }
   if (p.old_interp_flds_order) {
     if (p.static_icebergs) rc = launch_berg<PH_THERMO | PH_SPREAD>(h);
     else rc = launch_berg<PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);

@@ -104,7 +104,8 @@ class Icebergs:
         return s
 
     def upload_bergs(self, bergs):
-        s = self._soa(bergs)
+        """bergs["_n"] (optional) = number of live rows when the arrays carry spare rows"""
+        s = self._soa(bergs, bergs.get("_n"))
         self._check(self.lib.kid_upload_bergs(self.h, C.byref(s)), "kid_upload_bergs")
 
     def num_bergs(self):
@@ -119,6 +120,16 @@ class Icebergs:
         s = self._soa(b)
         self._check(self.lib.kid_download_bergs(self.h, C.byref(s)), "kid_download_bergs")
         return b
+
+    def set_iceberg_counter(self, counter):
+        a = np.ascontiguousarray(counter, dtype=np.int32)
+        assert a.shape == (self.nj, self.ni)
+        self._check(self.lib.kid_set_iceberg_counter(self.h, a.ctypes.data_as(C.POINTER(C.c_int32))), "kid_set_iceberg_counter")
+
+    def get_iceberg_counter(self):
+        a = np.zeros((self.nj, self.ni), dtype=np.int32)
+        self._check(self.lib.kid_get_iceberg_counter(self.h, a.ctypes.data_as(C.POINTER(C.c_int32))), "kid_get_iceberg_counter")
+        return a
 
     def move_berg_between_cells(self):
         """IB:5437: re-bin (stable sort by cell, dead bergs dropped)."""

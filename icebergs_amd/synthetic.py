@@ -239,13 +239,73 @@ def config_c2(n=1_000_000, seed=2, continents=False):
     return grid, p, b
 
 
+def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3, dt=600.0):
+    """BASELINE config 3, the footloose profile of tests/footloose_tests/input.nml: Cartesian 1 km grid, Verlet,
+    footloose calving into FL bits (or child bergs), 300 m thick tabular bergs with +-20 % jitter, ocean 1 m/s east,
+    wind stress -1 (about -25.8 m/s as a wind), SST -0.5.  The arrays carry spare rows for children (b["_n"] live).
+    fl_k starts at a random fraction of a foot so that calving starts within tens of steps."""
+    grid = cartesian_grid(ni, nj, 1000.0, Lx=-1.0)
+    F = grid["forcing"]
+    F["uo"][:] = 1.0
+    jmid = F["vo"].shape[0] // 2
+    F["vo"][:jmid] = 0.1
+    F["vo"][jmid:] = -0.1
+    F["ua"][:] = -25.8
+    F["sst"][:] = -0.5
+    F["sss"][:] = 34.0
+    p = default_params()
+    p.dt, p.lat_ref, p.use_f_plane = dt, -70.0, 1
+    p.Runge_not_Verlet = 0
+    p.footloose, p.displace_fl_bergs = 1, 0
+    p.fl_style = T.ENUMS["KID_FL_STYLE_FL_BITS" if fl_style == "fl_bits" else "KID_FL_STYLE_NEW_BERGS"]
+    p.fl_youngs, p.fl_strength = 1.0e8, 250.0
+    p.new_berg_from_fl_bits_mass_thres = 3.0e11
+    p.bergy_bit_erosion_fraction = 1.0
+    p.use_updated_rolling_scheme, p.allow_bergs_to_roll = 1, 1
+    p.old_bug_bilin, p.use_old_spreading, p.add_weight_to_ocean = 0, 0, 0
+    p.use_new_predictive_corrective, p.const_gamma = 1, 0
+    p.ustar_icebergs_bg = 0.0
+    p.apply_thickness_cutoff_to_gridded_melt, p.apply_thickness_cutoff_to_bergs_melt, p.melt_cutoff = 1, 1, 10.0
+    p.old_interp_flds_order = 0
+    rng = np.random.default_rng(seed)
+    cap = max(capacity_factor * n, n + 64)
+    b = empty_bergs(cap)
+    b["alive"][n:] = 0
+    d = grid["desc"]
+    i = rng.integers(d.isc + 3, d.isc + max(4, (d.iec - d.isc) // 3), size=n).astype(np.int32)  # western third: they drift east
+    j = rng.integers(d.jsc + 4, d.jec - 3, size=n).astype(np.int32)
+    xi, yj = rng.uniform(0.05, 0.95, n), rng.uniform(0.05, 0.95, n)
+    b["ine"][:n], b["jne"][:n], b["xi"][:n], b["yj"][:n] = i, j, xi, yj
+    b["lon"][:n] = (i - 1 + xi) * 1000.0
+    b["lat"][:n] = (j - 1 + yj) * 1000.0
+    Tk = 300.0 * rng.uniform(0.8, 1.2, n)
+    W = rng.uniform(3000.0, 6000.0, n)
+    L = W * rng.uniform(1.0, 1.5, n)
+    b["thickness"][:n], b["width"][:n], b["length"][:n] = Tk, W, L
+    b["mass"][:n] = Tk * W * L * RHO_BERGS
+    b["start_mass"][:n] = b["mass"][:n]
+    b["mass_scaling"][:n] = 1.0
+    b["start_lon"][:n], b["start_lat"][:n] = b["lon"][:n], b["lat"][:n]
+    b["lon_old"][:n], b["lat_old"][:n] = b["lon"][:n], b["lat"][:n]
+    b["start_year"][:n] = 1
+    b["start_day"][:n] = rng.uniform(0.0, 10.0, n)
+    b["fl_k"][:n] = rng.uniform(0.0, 6.0e4, n)
+    if fl_style == "fl_bits":  # some bergs already carry FL bits close to the new-berg threshold
+        b["mass_of_fl_bits"][:n] = np.where(rng.uniform(size=n) < 0.3, rng.uniform(1.0e11, 2.9e11, n), 0.0)
+        b["mass_of_fl_bergy_bits"][:n] = 0.01 * b["mass_of_fl_bits"][:n]
+    b["uvel"][:n] = 0.5
+    b["uvel_old"][:n] = 0.5
+    b["_n"] = n
+    return grid, p, b
+
+
 def set_diag_all(p):
     p.diag_mask = (1 << 20) - 1
     return p
 
 
 def copy_bergs(b):
-    return {k: v.copy() for k, v in b.items()}
+    return {k: (v.copy() if hasattr(v, "copy") else v) for k, v in b.items()}
 
 
 def params_copy(p):

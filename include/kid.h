@@ -82,6 +82,10 @@ int kid_footloose_calving(kid_handle *h);
 int kid_thermodynamics(kid_handle *h);
 int kid_create_gridded_icebergs_fields(kid_handle *h);
 
+/* grd%iceberg_counter_grd (FW:1017), the per-cell counter generate_id draws berg ids from; (isd:ied,jsd:jed) int32 */
+int kid_set_iceberg_counter(kid_handle *h, const int32_t *counter);
+int kid_get_iceberg_counter(kid_handle *h, int32_t *counter);
+
 /* ---- the hot path, fused: one launch does evolve + thermodynamics + mass spreading per berg ---- */
 int kid_step_local(kid_handle *h);   /* zero accumulators, per-berg kernel(s); accumulators hold LOCAL sums */
 int kid_step_gather(kid_handle *h);  /* 9-point gather + derived fields (after the cross-GPU all-reduce) */

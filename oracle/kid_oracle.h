@@ -16,6 +16,7 @@ typedef struct ko_grid {
   kid_grid_desc d;
   const double *stat[KID_NGRID_STATIC];   /* static grid fields  */
   const double *forc[KID_NFORCING];       /* forcing fields      */
+  int32_t *iceberg_counter;               /* grd%iceberg_counter_grd (FW:1017), per cell; may be NULL without footloose */
 } ko_grid;
 
 /* geometry (icebergs_framework.F90) */

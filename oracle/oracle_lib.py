@@ -17,7 +17,8 @@ from icebergs_amd import types as T  # noqa: E402  (interface types only)
 class KoGrid(C.Structure):
     _fields_ = [("d", T.GridDesc),
                 ("stat", C.POINTER(C.c_double) * T.ENUMS["KID_NGRID_STATIC"]),
-                ("forc", C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"])]
+                ("forc", C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"]),
+                ("iceberg_counter", C.POINTER(C.c_int32))]
 
 
 def build():
@@ -106,6 +107,8 @@ class Oracle:
         ni = grid["desc"].ied - grid["desc"].isd + 1
         nj = grid["desc"].jed - grid["desc"].jsd + 1
         self.ni, self.nj = ni, nj
+        self.iceberg_counter = np.zeros((nj, ni), dtype=np.int32)
+        self.kg.iceberg_counter = self.iceberg_counter.ctypes.data_as(C.POINTER(C.c_int32))
         self.acc = np.zeros((T.NACC, nj, ni))
         self.out = np.zeros((T.NOUT, nj, ni))
         self.scalars = np.zeros(T.NSCALAR)
@@ -119,8 +122,9 @@ class Oracle:
 
     @staticmethod
     def soa(bergs):
+        """bergs["_n"] (optional) = number of live rows when the arrays carry spare capacity for footloose children"""
         s = T.BergSoA()
-        n = len(bergs["lon"])
+        n = int(bergs.get("_n", len(bergs["lon"])))
         s.n = n
         for k, name in enumerate(T.BERG_F64_NAMES):
             a = bergs[name]
@@ -145,4 +149,6 @@ class Oracle:
         for _ in range(nsteps):
             self.lib.ko_run_step(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]),
                                  _dp(self.acc), _dp(self.out), _dp(self.scalars))
+        if "_n" in bergs:
+            bergs["_n"] = int(s.n)  # footloose calving appends children
         return bergs

@@ -171,3 +171,54 @@ def test_move_berg_between_cells(oracle):
         base = res[0][0][f][res[0][0]["alive"] != 0][order[0]]
         for r, o in zip(res[1:], order[1:]):
             assert np.array_equal(base, r[0][f][r[0]["alive"] != 0][o]), f
+
+
+@pytest.mark.parametrize("style", ["fl_bits", "new_bergs"])
+@pytest.mark.parametrize("mode", ["fused", "phases"])
+def test_c3_footloose(oracle, style, mode):
+    """BASELINE config 3 (tests/footloose_tests profile): Verlet + footloose calving into FL bits (with new bergs
+    spawned from the bits above 3e11 kg) or directly into child bergs; children are appended to the SoA with ids
+    from the per-cell counter (generate_id)."""
+    grid, p, b = S.config_c3(n=400, seed=3, fl_style=style)
+    S.set_diag_all(p)
+    ref, got = _both(grid, p, b, 40, mode)
+    P.compare(ref, got, "C3/%s/%s" % (style, mode))
+    from icebergs_amd import types as T
+    ncalved = ref[3][T.SCALAR_NAMES["nbergs_calved_fl"]]
+    assert ncalved >= 5, ncalved
+    assert ref[0]["_n"] == len(got[0]["lon"]) or (got[0]["alive"] != 0).sum() == (ref[0]["alive"][:ref[0]["_n"]] != 0).sum()
+
+
+def test_c3_footloose_capacity_error(oracle):
+    """children need spare rows: without them kid_footloose_calving reports KID_ECAPACITY instead of writing
+    past the arrays"""
+    from icebergs_amd.framework import Icebergs
+    from icebergs_amd.lib import KidError
+    grid, p, b = S.config_c3(n=200, seed=4, fl_style="new_bergs")
+    ib = Icebergs(grid, p, capacity=200, device=0)
+    try:
+        ib.upload_bergs(b)
+        with pytest.raises(KidError) as e:
+            ib.run(40)
+        assert "capacity" in str(e.value)
+    finally:
+        ib.close()
+
+
+def test_c3_iceberg_counter_roundtrip(oracle):
+    grid, p, b = S.config_c3(n=50, seed=5, fl_style="new_bergs")
+    from icebergs_amd.framework import Icebergs
+    ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
+    try:
+        c0 = np.arange(ib.ni * ib.nj, dtype=np.int32).reshape(ib.nj, ib.ni)
+        ib.set_iceberg_counter(c0)
+        assert np.array_equal(ib.get_iceberg_counter(), c0)
+        ib.upload_bergs(b)
+        ib.run(30)
+        c1 = ib.get_iceberg_counter()
+        got = ib.download_bergs()
+        nchild = int((got["id"] >= (1 << 32)).sum())
+        assert nchild > 0 and int((c1 - c0).sum()) >= nchild  # every child drew one counter value
+        assert len(np.unique(got["id"])) == len(got["id"])
+    finally:
+        ib.close()

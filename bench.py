@@ -79,6 +79,7 @@ def main():
     ib = Icebergs(grid, params, capacity=args.bergs, device=local_rank)
     ib.set_stream(torch.cuda.current_stream().cuda_stream)
     ib.upload_bergs(bergs)
+    ib.set_store_environment(False)  # config 2 runs with ignore_traj=T: nobody reads berg%uo..hi (see include/kid.h)
     # forcing planes resident on the device (as an ocean/ice model on the same GPU would hand them over)
     forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
     forcing_ptrs = [t.data_ptr() for t in forcing_dev]
@@ -122,18 +123,29 @@ def main():
         value = total_bergs * args.steps / elapsed
         kern_ms = berg_ms / max(launches, 1)
         achieved = ALGO_BYTES_PER_BERG_STEP * args.bergs / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is
+        # the committed rocprofv3 --pmc measurement of this same command (profiles/r01_hbm_traffic.json), valid only
+        # for the population it was taken at
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                tj = json.load(f)
+            if tj["bergs_per_launch"] == args.bergs:
+                traffic, traffic_src = tj["hbm_traffic_bytes_per_launch"], "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; gfx950 fetch correction x2)"
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "berg_steps_per_sec", "value": value, "unit": "berg-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
-                                   "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s" % args.bergs,
+                                   "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s, ignore_traj=T" % args.bergs,
                        "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
                        "exchange": "RCCL all-reduce of %d per-cell planes (%.1f MB) per step" % (T.ENUMS["KID_NACC_CORE"], ncore * 8 / 1e6) if world > 1 else "none (1 GPU)",
                        "bergs_alive_at_end": n_alive},
             "per_gpu_value": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "berg_kernel<true, true, 14u, true> (RK4, old interp order, evolve|thermo|spread, hot build)",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "berg_kernel<true, true, 14u, true> (RK4, old interp order, evolve|thermo|spread, hot build)",
                          "kernel_ms_avg": kern_ms, "kernel_launches": launches,
                          "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
         }

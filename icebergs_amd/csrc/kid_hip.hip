@@ -556,6 +556,7 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   if (rc) return rc;
   h->params = *params;
   h->tables_dirty = true;
+  if (!h->params.old_interp_flds_order) h->flags.store_env = 1;  // the stored environment is an input again
   return KID_OK;
 }
 int kid_set_stream(kid_handle *h, void *s) {
@@ -805,6 +806,13 @@ int kid_move_berg_between_cells(kid_handle *h) {
 int kid_set_resort_interval(kid_handle *h, int steps) {
   if (!h || steps < 0) return KID_EINVAL;
   h->resort_interval = steps;
+  return KID_OK;
+}
+
+int kid_set_store_environment(kid_handle *h, int on) {
+  if (!h) return KID_EINVAL;
+  if (!on && !h->params.old_interp_flds_order) { h->err = "the stored environment is an input unless old_interp_flds_order"; return KID_EINVAL; }
+  h->flags.store_env = on ? 1 : 0;
   return KID_OK;
 }
 

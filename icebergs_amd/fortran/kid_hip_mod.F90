@@ -97,6 +97,11 @@ module kid_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function kid_set_store_environment(h, on) bind(C, name='kid_set_store_environment')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function
     integer(c_int) function kid_set_iceberg_counter(h, counter) bind(C, name='kid_set_iceberg_counter')  ! grd%iceberg_counter_grd, FW:1017
       import :: c_int, c_ptr, c_int32_t
       type(c_ptr), value :: h

@@ -121,6 +121,9 @@ class Icebergs:
         self._check(self.lib.kid_download_bergs(self.h, C.byref(s)), "kid_download_bergs")
         return b
 
+    def set_store_environment(self, on):
+        self._check(self.lib.kid_set_store_environment(self.h, 1 if on else 0), "kid_set_store_environment")
+
     def set_iceberg_counter(self, counter):
         a = np.ascontiguousarray(counter, dtype=np.int32)
         assert a.shape == (self.nj, self.ni)

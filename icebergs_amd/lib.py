@@ -17,7 +17,7 @@ SYMBOLS = [
     "kid_sizeof", "kid_set_static_grid", "kid_set_forcing", "kid_set_forcing_device", "kid_upload_bergs", "kid_download_bergs",
     "kid_num_bergs", "kid_compact_bergs", "kid_move_berg_between_cells", "kid_set_resort_interval", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
     "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
-    "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
+    "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
     "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
 ]
 
@@ -67,6 +67,7 @@ def load():
                  "kid_create_gridded_icebergs_fields", "kid_step_local", "kid_step_gather"):
         getattr(lib, name).argtypes = [H]
     lib.kid_run_step.argtypes = [H, C.c_int]
+    lib.kid_set_store_environment.argtypes = [H, C.c_int]
     lib.kid_set_iceberg_counter.argtypes = [H, C.POINTER(C.c_int32)]
     lib.kid_get_iceberg_counter.argtypes = [H, C.POINTER(C.c_int32)]
     lib.kid_get_accumulators.argtypes = [H, dp, dp, dp]

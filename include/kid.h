@@ -74,6 +74,12 @@ int kid_compact_bergs(kid_handle *h);                                 /* drop me
 int kid_move_berg_between_cells(kid_handle *h);
 int kid_set_resort_interval(kid_handle *h, int steps);
 
+/* berg%uo..od (the last interpolated environment).  With old_interp_flds_order accel re-interpolates (IB:2035) and the
+ * stored copy is read only by trajectory records (FW:5422) and bergs_chksum (FW:7040): a run with ignore_traj=T may
+ * switch it off (on = 0) and save 13 stores per berg per step.  Refused (KID_EINVAL at launch) when the stored
+ * environment is an input, i.e. .not.old_interp_flds_order.  Default on. */
+int kid_set_store_environment(kid_handle *h, int on);
+
 /* ---- the hot path, phase by phase (same order as icebergs_run, IB:5423-5512) ---- */
 int kid_zero_accumulators(kid_handle *h);
 int kid_interp_gridded_fields_to_bergs(kid_handle *h);

@@ -52,6 +52,13 @@ def default_params():
     p.fl_style = T.ENUMS["KID_FL_STYLE_NEW_BERGS"]
     p.fl_bits_erosion_to_bergy_bits = 1
     p.displace_fl_bergs = 1
+    # interactions / MTS / DEM (FW:693-705, 772-812)
+    p.spring_coef = p.contact_spring_coef = 1.0e-8
+    p.contact_distance, p.radial_damping_coef, p.tangental_damping_coef = 0.0, 1.0e-4, 2.0e-5
+    p.convergence_tolerance, p.dem_damping_coef, p.poisson = 1.0e-8, 0.1, 0.3
+    p.scale_damping_by_pmag = p.critical_interaction_damping_on = p.tang_crit_int_damp_on = 1
+    p.contact_cells_lon = p.contact_cells_lat = 1
+    p.max_bonds, p.mts_sub_steps = 6, 1
     return p
 
 
@@ -297,6 +304,126 @@ def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3
     b["uvel_old"][:n] = 0.5
     b["_n"] = n
     return grid, p, b
+
+
+def empty_bonds(n, max_bonds=6):
+    """Bond lists of n bergs flattened slot-major (include/kid_types.h kid_bond_soa)."""
+    bd = {"max_bonds": max_bonds, "count": np.zeros(n, dtype=np.int32),
+          "other_id": np.zeros(max_bonds * n, dtype=np.int64), "broken": np.zeros(max_bonds * n, dtype=np.int32)}
+    for name in T.BOND_F64_NAMES:
+        bd[name] = np.zeros(max_bonds * n)
+    return bd
+
+
+def bond_neighbours(b, n, reach, max_bonds=6):
+    """Bond every pair of bergs closer than `reach` (what initialize_iceberg_bonds does for a packed conglomerate,
+    IB:356-441); a berg's bonds are listed by increasing partner row."""
+    bd = empty_bonds(len(b["lon"]), max_bonds)
+    N = len(b["lon"])
+    x, y = b["lon"][:n], b["lat"][:n]
+    for k in range(n):
+        d2 = (x - x[k]) ** 2 + (y - y[k]) ** 2
+        near = np.nonzero((d2 < reach * reach) & (np.arange(n) != k))[0]
+        assert len(near) <= max_bonds, (k, len(near))
+        for s, o in enumerate(near):
+            bd["other_id"][s * N + k] = b["id"][o]
+        bd["count"][k] = len(near)
+        b["n_bonds"][k] = len(near)
+    return bd
+
+
+def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45, nj=45, gridres=5000.0, sub_steps=200,
+              bump=(58.0e3, 60.0e3), bump_depth=50.0, origin=(44.0e3, 35.0e3), frac=(1850.0, 1000.0), thickness_jitter=0.0,
+              seed=4, two_bergs=False):
+    """BASELINE config 4 family: a tabular berg made of bonded DEM elements (hexagonal or square packing) drifting at
+    0.1 m/s onto a Gaussian seamount on the Cartesian grid of tests/dem_ground_frac_test (driver DRV:288-307,
+    namelist tests/dem_ground_frac_test/input.nml): MTS velocity Verlet with explicit DEM sub-steps, stress fracture
+    on the sub-steps, broken bonds kept for contact, grounding drag on the sub-steps.
+    Differences from that namelist (not built): coastal_drift=0 and no land rows, rotate_icebergs_for_mass_spreading=F,
+    melt rates are computed (set_melt_rates_to_zero=T there)."""
+    grid = cartesian_grid(ni, nj, gridres, Lx=-1.0)
+    d = grid["desc"]
+    ii, jj = _ij(d)
+    xc, yc = gridres * ii - gridres / 2.0, gridres * jj - gridres / 2.0
+    a, cw = 1000.0 - bump_depth, 5.0e3
+    grid["static"]["ocean_depth"][:] = 1000.0 - a * np.exp(-((xc - bump[0]) ** 2 / (2 * cw * cw) + (yc - bump[1]) ** 2 / (2 * cw * cw)))
+    F = grid["forcing"]
+    F["uo"][:] = 0.1
+    F["vo"][:] = 0.1
+    F["sst"][:] = -1.0
+    F["sss"][:] = 34.0
+    p = default_params()
+    p.dt, p.lat_ref, p.use_f_plane = 1800.0, 0.0, 0
+    p.Runge_not_Verlet, p.old_interp_flds_order, p.use_new_predictive_corrective = 0, 0, 1
+    p.old_bug_bilin, p.use_old_spreading = 0, 0
+    p.mts, p.dem, p.explicit_inner_mts, p.mts_sub_steps = 1, 1, 1, sub_steps
+    p.iceberg_bonds_on, p.interactive_icebergs_on, p.internal_bergs_for_drag = 1, 1, 1
+    p.use_broken_bonds_for_substep_contact, p.break_bonds_on_sub_steps, p.short_step_mts_grounding = 1, 1, 1
+    p.constant_interaction_LW, p.force_convergence, p.convergence_tolerance = 1, 1, 1.0e-2
+    p.hexagonal_icebergs = 1 if hexagonal else 0
+    p.max_bonds = 6 if hexagonal else 4
+    p.poisson, p.dem_damping_coef, p.dem_spring_coef = 0.3, 1.0, 5.0e6
+    p.spring_coef = 0.0007547062342348049
+    p.contact_distance, p.contact_spring_coef = 4.0e3, 5.0e-8
+    p.contact_cells_lon = p.contact_cells_lat = 1  # ceil(4e3 / 5e3)
+    p.cdrag_grounding, p.h_to_init_grounding = 1.0e4, 0.0
+    p.fracture_criterion_stress, p.frac_thres_n, p.frac_thres_t = 1, frac[0], frac[1]
+    p.radial_damping_coef = p.tangental_damping_coef = 0.0
+    p.scale_damping_by_pmag, p.critical_interaction_damping_on, p.tang_crit_int_damp_on = 0, 1, 0
+    p.use_updated_rolling_scheme, p.allow_bergs_to_roll = 1, 1
+    p.ustar_icebergs_bg, p.const_gamma = 0.0, 0
+    p.apply_thickness_cutoff_to_gridded_melt, p.apply_thickness_cutoff_to_bergs_melt, p.melt_cutoff = 1, 1, 10.0
+    # elements
+    xs, ys = [], []
+    if hexagonal:
+        for jcol in range(nx):
+            for krow in range(ny):
+                xs.append(origin[0] + radius * 2.0 / np.sqrt(3.0) + np.sqrt(3.0) * radius * jcol)
+                ys.append(origin[1] + radius + (jcol % 2) * radius + 2 * krow * radius)
+        area = (3.0 * np.sqrt(3.0) / 2.0) * ((4.0 / 3.0) * radius ** 2)
+    else:
+        for jcol in range(nx):
+            for krow in range(ny):
+                xs.append(origin[0] + radius + 2 * radius * jcol)
+                ys.append(origin[1] + radius + 2 * radius * krow)
+        area = (2.0 * radius) ** 2
+    if two_bergs:  # a second, smaller conglomerate just east of the first: collisions between conglomerates
+        x0 = max(xs) + 3.2 * radius
+        for jcol in range(2):
+            for krow in range(3):
+                xs.append(x0 + 2 * radius * jcol)
+                ys.append(origin[1] + radius + 2 * radius * (krow + ny // 2 - 1))
+    n = len(xs)
+    first = nx * ny
+    rng = np.random.default_rng(seed)
+    b = empty_bergs(n)
+    b["lon"][:], b["lat"][:] = xs, ys
+    b["ine"][:] = np.floor(b["lon"] / gridres).astype(np.int32) + 1
+    b["jne"][:] = np.floor(b["lat"] / gridres).astype(np.int32) + 1
+    b["xi"][:] = b["lon"] / gridres - (b["ine"] - 1)
+    b["yj"][:] = b["lat"] / gridres - (b["jne"] - 1)
+    w = np.sqrt(area)
+    Tk = thickness * (1.0 + thickness_jitter * rng.uniform(-1.0, 1.0, n))
+    b["thickness"][:], b["width"][:], b["length"][:] = Tk, w, w
+    b["mass"][:] = Tk * RHO_BERGS * area
+    b["start_mass"][:] = b["mass"]
+    b["mass_scaling"][:] = 1.0
+    b["uvel"][:first] = 0.1
+    b["uvel"][first:] = -0.05
+    for f in ("uvel_old", "uvel_prev"):
+        b[f][:] = b["uvel"]
+    b["lon_old"][:], b["lat_old"][:] = b["lon"], b["lat"]
+    b["start_lon"][:], b["start_lat"][:] = b["lon"], b["lat"]
+    b["start_year"][:] = 1
+    b["start_day"][:] = 1.0e-6 * np.arange(n)
+    p.constant_length = p.constant_width = float(w)
+    b = sort_reference_order(b)
+    bd = bond_neighbours(b, n, 2.0 * radius * 1.05, p.max_bonds)
+    return grid, p, b, bd
+
+
+def copy_bonds(bd):
+    return {k: (v.copy() if hasattr(v, "copy") else v) for k, v in bd.items()}
 
 
 def set_diag_all(p):

@@ -75,6 +75,12 @@ class BergSoA(C.Structure):
     _fields_ = _parse_struct(_src, "kid_berg_soa", ENUMS)
 
 
+class BondSoA(C.Structure):
+    _fields_ = _parse_struct(_src, "kid_bond_soa", ENUMS)
+
+
+BOND_F64_NAMES = [k[len("KID_BOND_"):].lower() for k, v in sorted(
+    ((k, v) for k, v in ENUMS.items() if k.startswith("KID_BOND_")), key=lambda kv: kv[1])]
 BERG_F64_NAMES = [k[len("KID_B_"):].lower() for k, v in sorted(
     ((k, v) for k, v in ENUMS.items() if k.startswith("KID_B_")), key=lambda kv: kv[1])]
 BERG_I32_NAMES = [k[len("KID_BI_"):].lower() for k, v in sorted(

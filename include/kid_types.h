@@ -59,10 +59,12 @@ enum {
   /* environment as seen by the berg (FW:331-343) */
   KID_B_UO, KID_B_VO, KID_B_UI, KID_B_VI, KID_B_UA, KID_B_VA,
   KID_B_SSH_X, KID_B_SSH_Y, KID_B_SST, KID_B_SSS, KID_B_CN, KID_B_HI, KID_B_OD,
+  /* multiple-time-stepping / DEM extras (FW:348-358) */
+  KID_B_AXN_FAST, KID_B_AYN_FAST, KID_B_BXN_FAST, KID_B_BYN_FAST, KID_B_ANG_VEL, KID_B_ANG_ACCEL, KID_B_ROT,
   KID_NB_F64
 };
 /* ---- per-berg int32 fields ---- */
-enum { KID_BI_INE = 0, KID_BI_JNE, KID_BI_START_YEAR, KID_BI_N_BONDS, KID_BI_ALIVE, KID_NB_I32 };
+enum { KID_BI_INE = 0, KID_BI_JNE, KID_BI_START_YEAR, KID_BI_N_BONDS, KID_BI_ALIVE, KID_BI_CONGLOM_ID, KID_NB_I32 };
 
 /* Structure of arrays: one contiguous array of length n per field.  A NULL pointer on upload means
  * "all zero"; on download it means "do not copy this field back". */
@@ -72,6 +74,24 @@ typedef struct kid_berg_soa {
   int32_t *i32[KID_NB_I32];
   int64_t *id;               /* FW:325 integer(kind=8) :: id */
 } kid_berg_soa;
+
+/* ---- bonds (type bond, FW:362-386): the per-berg linked list first_bond -> next_bond flattened to `count[k]` slots,
+ * in list order.  Arrays are slot-major: x[s * n + k] is slot s of berg k, s < max_bonds.  A bond exists on both of
+ * its bergs (the reference's matching `other_bond`); the library re-derives row indices from other_id. ---- */
+enum {
+  KID_BOND_LENGTH = 0, KID_BOND_TANGD1, KID_BOND_TANGD2, KID_BOND_NSTRESS, KID_BOND_SSTRESS, KID_BOND_REL_ROTATION,
+  KID_BOND_F_X, KID_BOND_F_Y, KID_BOND_FD_X, KID_BOND_FD_Y, KID_BOND_T, KID_BOND_T_D,   /* save_bond_forces, FW:379-385 */
+  KID_NBOND_F64
+};
+enum { KID_MAX_BONDS = 6 };                /* max_bonds FW:693 */
+typedef struct kid_bond_soa {
+  int64_t  n;                              /* bergs (rows) */
+  int32_t  max_bonds; int32_t pad;         /* slots per berg, <= KID_MAX_BONDS */
+  int32_t *count;                          /* [n] bonds in berg k's list, broken ones included */
+  int64_t *other_id;                       /* [max_bonds*n] FW:367 */
+  int32_t *broken;                         /* [max_bonds*n] FW:377 */
+  double  *f64[KID_NBOND_F64];             /* [max_bonds*n] each; NULL = zero on upload / skip on download */
+} kid_bond_soa;
 
 /* ---- per-cell accumulators written by the hot path (zeroed at IB:5125-5156) ----
  * Planes that are always live come first (KID_NACC_CORE of them): that prefix is what gets zeroed each step
@@ -112,6 +132,7 @@ enum {
   KID_S_NSPEEDING_TICKETS,      /* IB:2314 */
   KID_S_NBERGS_ALIVE,           /* bookkeeping of the SoA (not in the reference) */
   KID_S_ERROR_COUNT,            /* bergs that hit a reference FATAL/WARNING path (e.g. IB:3207, FW:6502) */
+  KID_S_NBONDS_BROKEN,          /* bond sides that fractured (bond_break_detected IB:1144, counted) */
   KID_NSCALAR = 8
 };
 
@@ -176,6 +197,18 @@ typedef struct kid_params {
   double u_override, v_override;  /* FW:710-711 */
   double initial_mass_s[10];      /* FW:787 */
   double initial_mass_n[10];      /* FW:793 */
+  /* interactions, multiple time stepping, DEM (values as left by ice_bergs_framework_init) */
+  double spring_coef;             /* FW:695 */
+  double contact_spring_coef;     /* FW:696 (= spring_coef when the namelist leaves it 0) */
+  double contact_distance;        /* FW:782 */
+  double radial_damping_coef;     /* FW:704 */
+  double tangental_damping_coef;  /* FW:705 */
+  double convergence_tolerance;   /* FW:785 */
+  double constant_length, constant_width; /* FW:811-812 */
+  double dem_spring_coef;         /* FW:804 */
+  double dem_damping_coef;        /* FW:805 */
+  double poisson;                 /* FW:803 */
+  double frac_thres_n, frac_thres_t; /* FW:1355-1356 (already scaled by frac_thres_scaling) */
   /* switches (0/1) */
   int32_t Runge_not_Verlet;             /* FW:733 */
   int32_t use_new_predictive_corrective;/* FW:770 */
@@ -214,6 +247,24 @@ typedef struct kid_params {
   int32_t pass_fields_to_ocean_model;   /* FW:739 */
   int32_t static_icebergs;              /* FW:756 */
   int32_t old_bug_rotated_weights;      /* FW:38  */
+  int32_t mts_sub_steps;                /* FW:780, 1296-1301 (>0; mts_fast_dt = dt/mts_sub_steps) */
+  int32_t explicit_inner_mts;           /* FW:784 (forced on by dem, FW:1433) */
+  int32_t force_convergence;            /* FW:783 */
+  int32_t critical_interaction_damping_on; /* FW:773 */
+  int32_t tang_crit_int_damp_on;        /* FW:774 */
+  int32_t scale_damping_by_pmag;        /* FW:772 */
+  int32_t contact_cells_lon, contact_cells_lat; /* FW:1514-1518 */
+  int32_t constant_interaction_LW;      /* FW:810 */
+  int32_t ignore_tangential_force;      /* FW:802 */
+  int32_t fracture_criterion_stress;    /* FW:800: 1 = 'stress', 0 = 'none' */
+  int32_t max_bonds;                    /* FW:693 */
+  int32_t use_broken_bonds_for_substep_contact; /* FW:806, 1439-1447 */
+  int32_t break_bonds_on_sub_steps;     /* FW:61 */
+  int32_t short_step_mts_grounding;     /* FW:54 */
+  int32_t use_grounding_torque;         /* FW:801 */
+  int32_t radius_based_drag;            /* FW:55 */
+  int32_t orig_dem_moment_of_inertia;   /* FW:60 */
+  int32_t rev_mind;                     /* FW:59 */
   int32_t diag_mask;                    /* KID_DIAG_* : which `id_*>0` guards are on */
   int32_t pad1[2];
 } kid_params;

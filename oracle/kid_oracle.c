@@ -82,6 +82,11 @@ void ko_default_params(kid_params *p) {
   p->Use_three_equation_model = 1; p->const_gamma = 1; p->use_roundoff_fix = 1;
   p->fl_style = KID_FL_STYLE_NEW_BERGS; p->fl_bits_erosion_to_bergy_bits = 1; p->displace_fl_bergs = 1;
   p->diag_mask = 0;
+  /* interactions / MTS / DEM, FW:693-705, 772-812 */
+  p->spring_coef = 1.e-8; p->contact_spring_coef = 1.e-8; p->contact_distance = 0.; p->radial_damping_coef = 1.e-4;
+  p->tangental_damping_coef = 2.e-5; p->convergence_tolerance = 1.e-8; p->dem_damping_coef = 0.1; p->poisson = 0.3;
+  p->scale_damping_by_pmag = 1; p->critical_interaction_damping_on = 1; p->tang_crit_int_damp_on = 1;
+  p->contact_cells_lon = 1; p->contact_cells_lat = 1; p->max_bonds = 6; p->mts_sub_steps = 1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -286,7 +291,6 @@ enum { E_UO = 0, E_VO, E_UI, E_VI, E_UA, E_VA, E_SSHX, E_SSHY, E_SST, E_SSS, E_C
 /* IB:4718-4900 interp_flds (non-MTS: od = ocean_depth+ssh PCM; tidal_drift=0 (rx=ry=0)) */
 void ko_interp_flds(const ko_grid *g, const kid_params *p, double x, double y, int i, int j, double xi, double yj,
                     double env[13]) {
-  (void)x; (void)y;
   double cos_rot = ko_bilin(g, p, g->stat[KID_G_COS], i, j, xi, yj);
   double sin_rot = ko_bilin(g, p, g->stat[KID_G_SIN], i, j, xi, yj);
   double uo = ko_bilin(g, p, g->forc[KID_F_UO], i, j, xi, yj);
@@ -330,7 +334,8 @@ void ko_interp_flds(const ko_grid *g, const kid_params *p, double x, double y, i
   if (ssh_y != ssh_y) ssh_y = 0.;
   env[E_UO] = uo; env[E_VO] = vo; env[E_UI] = ui; env[E_VI] = vi; env[E_UA] = ua; env[E_VA] = va;
   env[E_SSHX] = ssh_x; env[E_SSHY] = ssh_y; env[E_SST] = sst; env[E_SSS] = sss; env[E_CN] = cn; env[E_HI] = hi;
-  env[E_OD] = GS(g, KID_G_OCEAN_DEPTH, i, j) + GF(g, KID_F_SSH, i, j); /* IB:4897 */
+  if (p->mts) env[E_OD] = ko_quad_interp_depth(g, p, x, y, i, j, xi, yj); /* IB:4894 */
+  else env[E_OD] = GS(g, KID_G_OCEAN_DEPTH, i, j) + GF(g, KID_F_SSH, i, j); /* IB:4897 */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -520,32 +525,32 @@ void ko_adjust_index_and_ground(const ko_grid *g, const kid_params *p, double *l
 }
 
 /* IB:462-477 */
-static void meters_to_grid(const ko_grid *g, const kid_params *p, double lat_ref, double *dlon_dx, double *dlat_dy) {
+void ko_meters_to_grid(const ko_grid *g, const kid_params *p, double lat_ref, double *dlon_dx, double *dlat_dy) {
   if (g->d.grid_is_latlon) {
     *dlon_dx = (180. / p->pi) / (p->Rearth * cos((lat_ref) * (p->pi / 180.)));
     *dlat_dy = (180. / p->pi) / p->Rearth;
   } else { *dlon_dx = 1.; *dlat_dy = 1.; }
 }
 /* tangent plane helpers IB:7767-7816, 8066-8099 */
-static void rotpos_to_tang(const kid_params *p, double lon, double lat, double *x, double *y) {
+void ko_rotpos_to_tang(const kid_params *p, double lon, double lat, double *x, double *y) {
   const double pi_180 = p->pi / 180.;
   double colat = 90. - lat;
   double r = p->Rearth * (colat * pi_180);
   *x = r * cos(lon * pi_180); *y = r * sin(lon * pi_180);
 }
-static void rotpos_from_tang(const kid_params *p, double x, double y, double *lon, double *lat) {
+void ko_rotpos_from_tang(const kid_params *p, double x, double y, double *lon, double *lat) {
   const double r180_pi = 180. / p->pi;
   double r = sqrt(x * x + y * y);
   *lat = 90. - (r180_pi * r / p->Rearth);
   *lon = r180_pi * acos(x / r) * fsign1(y);
 }
-static void rotvec_to_tang(const kid_params *p, double lon, double uvel, double vvel, double *xdot, double *ydot) {
+void ko_rotvec_to_tang(const kid_params *p, double lon, double uvel, double vvel, double *xdot, double *ydot) {
   const double pi_180 = p->pi / 180.;
   double clon = cos(lon * pi_180), slon = sin(lon * pi_180);
   *xdot = -slon * uvel - clon * vvel;
   *ydot = clon * uvel - slon * vvel;
 }
-static void rotvec_from_tang(const kid_params *p, double lon, double xdot, double ydot, double *uvel, double *vvel) {
+void ko_rotvec_from_tang(const kid_params *p, double lon, double xdot, double ydot, double *uvel, double *vvel) {
   const double pi_180 = p->pi / 180.;
   double clon = cos(lon * pi_180), slon = sin(lon * pi_180);
   *uvel = -slon * xdot + clon * ydot;
@@ -572,56 +577,56 @@ static void rk4_step(const ko_grid *g, const kid_params *p, const double bs[], i
   double axn = bs[KID_B_AXN], ayn = bs[KID_B_AYN], bxn = 0., byn = 0.;
   double axn1 = axn, axn2 = axn, axn3 = axn, axn4 = axn, ayn1 = ayn, ayn2 = ayn, ayn3 = ayn, ayn4 = ayn;
   double lon1 = bs[KID_B_LON], lat1 = bs[KID_B_LAT], x1 = 0, y1 = 0;
-  if (on_tang) rotpos_to_tang(p, lon1, lat1, &x1, &y1);
-  double dxdl1, dydl; meters_to_grid(g, p, lat1, &dxdl1, &dydl);
+  if (on_tang) ko_rotpos_to_tang(p, lon1, lat1, &x1, &y1);
+  double dxdl1, dydl; ko_meters_to_grid(g, p, lat1, &dxdl1, &dydl);
   double uvel1 = bs[KID_B_UVEL], vvel1 = bs[KID_B_VVEL], xdot1 = 0, ydot1 = 0;
-  if (on_tang) rotvec_to_tang(p, lon1, uvel1, vvel1, &xdot1, &ydot1);
+  if (on_tang) ko_rotvec_to_tang(p, lon1, uvel1, vvel1, &xdot1, &ydot1);
   double u1 = uvel1 * dxdl1, v1 = vvel1 * dydl;
   double ax1, ay1, xddot1 = 0, yddot1 = 0, xddot1n = 0, yddot1n = 0;
   ko_accel(g, p, bs, nb, i, j, xi, yj, lat1, uvel1, vvel1, uvel1, vvel1, dt_2, &ax1, &ay1, &axn1, &ayn1, &bxn, &byn, tick);
-  if (on_tang) { rotvec_to_tang(p, lon1, ax1, ay1, &xddot1, &yddot1); rotvec_to_tang(p, lon1, axn1, ayn1, &xddot1n, &yddot1n); }
+  if (on_tang) { ko_rotvec_to_tang(p, lon1, ax1, ay1, &xddot1, &yddot1); ko_rotvec_to_tang(p, lon1, axn1, ayn1, &xddot1n, &yddot1n); }
   /* stage 2 */
   double lon2, lat2, uvel2, vvel2, x2, y2, xdot2 = 0, ydot2 = 0;
   if (on_tang) {
     x2 = x1 + dt_2 * xdot1; y2 = y1 + dt_2 * ydot1;
     xdot2 = xdot1 + dt_2 * xddot1; ydot2 = ydot1 + dt_2 * yddot1;
-    rotpos_from_tang(p, x2, y2, &lon2, &lat2); rotvec_from_tang(p, lon2, xdot2, ydot2, &uvel2, &vvel2);
+    ko_rotpos_from_tang(p, x2, y2, &lon2, &lat2); ko_rotvec_from_tang(p, lon2, xdot2, ydot2, &uvel2, &vvel2);
   } else { lon2 = lon1 + dt_2 * u1; lat2 = lat1 + dt_2 * v1; uvel2 = uvel1 + dt_2 * ax1; vvel2 = vvel1 + dt_2 * ay1; }
   i = i1; j = j1; xi = bs[KID_B_XI]; yj = bs[KID_B_YJ];
   ko_adjust_index_and_ground(g, p, &lon2, &lat2, &i, &j, &xi, &yj, &bounced, err);
-  double dxdl2; meters_to_grid(g, p, lat2, &dxdl2, &dydl);
+  double dxdl2; ko_meters_to_grid(g, p, lat2, &dxdl2, &dydl);
   double u2 = uvel2 * dxdl2, v2 = vvel2 * dydl;
   double ax2, ay2, xddot2 = 0, yddot2 = 0, xddot2n = 0, yddot2n = 0;
   ko_accel(g, p, bs, nb, i, j, xi, yj, lat2, uvel2, vvel2, uvel1, vvel1, dt_2, &ax2, &ay2, &axn2, &ayn2, &bxn, &byn, tick);
-  if (on_tang) { rotvec_to_tang(p, lon2, ax2, ay2, &xddot2, &yddot2); rotvec_to_tang(p, lon2, axn2, ayn2, &xddot2n, &yddot2n); }
+  if (on_tang) { ko_rotvec_to_tang(p, lon2, ax2, ay2, &xddot2, &yddot2); ko_rotvec_to_tang(p, lon2, axn2, ayn2, &xddot2n, &yddot2n); }
   /* stage 3 */
   double lon3, lat3, uvel3, vvel3, x3, y3, xdot3 = 0, ydot3 = 0;
   if (on_tang) {
     x3 = x1 + dt_2 * xdot2; y3 = y1 + dt_2 * ydot2;
     xdot3 = xdot1 + dt_2 * xddot2; ydot3 = ydot1 + dt_2 * yddot2;
-    rotpos_from_tang(p, x3, y3, &lon3, &lat3); rotvec_from_tang(p, lon3, xdot3, ydot3, &uvel3, &vvel3);
+    ko_rotpos_from_tang(p, x3, y3, &lon3, &lat3); ko_rotvec_from_tang(p, lon3, xdot3, ydot3, &uvel3, &vvel3);
   } else { lon3 = lon1 + dt_2 * u2; lat3 = lat1 + dt_2 * v2; uvel3 = uvel1 + dt_2 * ax2; vvel3 = vvel1 + dt_2 * ay2; }
   i = i1; j = j1; xi = bs[KID_B_XI]; yj = bs[KID_B_YJ];
   ko_adjust_index_and_ground(g, p, &lon3, &lat3, &i, &j, &xi, &yj, &bounced, err);
-  double dxdl3; meters_to_grid(g, p, lat3, &dxdl3, &dydl);
+  double dxdl3; ko_meters_to_grid(g, p, lat3, &dxdl3, &dydl);
   double u3 = uvel3 * dxdl3, v3 = vvel3 * dydl;
   double ax3, ay3, xddot3 = 0, yddot3 = 0, xddot3n = 0, yddot3n = 0;
   ko_accel(g, p, bs, nb, i, j, xi, yj, lat3, uvel3, vvel3, uvel1, vvel1, dt, &ax3, &ay3, &axn3, &ayn3, &bxn, &byn, tick);
-  if (on_tang) { rotvec_to_tang(p, lon3, ax3, ay3, &xddot3, &yddot3); rotvec_to_tang(p, lon3, axn3, ayn3, &xddot3n, &yddot3n); }
+  if (on_tang) { ko_rotvec_to_tang(p, lon3, ax3, ay3, &xddot3, &yddot3); ko_rotvec_to_tang(p, lon3, axn3, ayn3, &xddot3n, &yddot3n); }
   /* stage 4 */
   double lon4, lat4, uvel4, vvel4, x4, y4, xdot4 = 0, ydot4 = 0;
   if (on_tang) {
     x4 = x1 + dt * xdot3; y4 = y1 + dt * ydot3;
     xdot4 = xdot1 + dt * xddot3; ydot4 = ydot1 + dt * yddot3;
-    rotpos_from_tang(p, x4, y4, &lon4, &lat4); rotvec_from_tang(p, lon4, xdot4, ydot4, &uvel4, &vvel4);
+    ko_rotpos_from_tang(p, x4, y4, &lon4, &lat4); ko_rotvec_from_tang(p, lon4, xdot4, ydot4, &uvel4, &vvel4);
   } else { lon4 = lon1 + dt * u3; lat4 = lat1 + dt * v3; uvel4 = uvel1 + dt * ax3; vvel4 = vvel1 + dt * ay3; }
   i = i1; j = j1; xi = bs[KID_B_XI]; yj = bs[KID_B_YJ];
   ko_adjust_index_and_ground(g, p, &lon4, &lat4, &i, &j, &xi, &yj, &bounced, err);
-  double dxdl4; meters_to_grid(g, p, lat4, &dxdl4, &dydl);
+  double dxdl4; ko_meters_to_grid(g, p, lat4, &dxdl4, &dydl);
   double u4 = uvel4 * dxdl4, v4 = vvel4 * dydl;
   double ax4, ay4, xddot4 = 0, yddot4 = 0, xddot4n = 0, yddot4n = 0;
   ko_accel(g, p, bs, nb, i, j, xi, yj, lat4, uvel4, vvel4, uvel1, vvel1, dt, &ax4, &ay4, &axn4, &ayn4, &bxn, &byn, tick);
-  if (on_tang) { rotvec_to_tang(p, lon4, ax4, ay4, &xddot4, &yddot4); rotvec_to_tang(p, lon4, axn4, ayn4, &xddot4n, &yddot4n); }
+  if (on_tang) { ko_rotvec_to_tang(p, lon4, ax4, ay4, &xddot4, &yddot4); ko_rotvec_to_tang(p, lon4, axn4, ayn4, &xddot4n, &yddot4n); }
   /* combine IB:7597-7616 */
   if (on_tang) {
     double xn = x1 + dt_6 * ((xdot1 + xdot4) + 2. * (xdot2 + xdot3));
@@ -630,9 +635,9 @@ static void rk4_step(const ko_grid *g, const kid_params *p, const double bs[], i
     double ydotn = ydot1 + dt_6 * ((yddot1 + yddot4) + 2. * (yddot2 + yddot3));
     double xddotn = ((xddot1n + xddot4n) + 2. * (xddot2n + xddot3n)) / 6.;
     double yddotn = ((yddot1n + yddot4n) + 2. * (yddot2n + yddot3n)) / 6.;
-    rotpos_from_tang(p, xn, yn, lonn, latn);
-    rotvec_from_tang(p, *lonn, xdotn, ydotn, uveln, vveln);
-    rotvec_from_tang(p, *lonn, xddotn, yddotn, &axn, &ayn);
+    ko_rotpos_from_tang(p, xn, yn, lonn, latn);
+    ko_rotvec_from_tang(p, *lonn, xdotn, ydotn, uveln, vveln);
+    ko_rotvec_from_tang(p, *lonn, xddotn, yddotn, &axn, &ayn);
     /* bxn, byn keep the values left by the 4th accel call (the reference does not recompute them here) */
   } else {
     *lonn = bs[KID_B_LON] + dt_6 * ((u1 + u4) + 2. * (u2 + u3));
@@ -665,10 +670,10 @@ static void verlet_step(const ko_grid *g, const kid_params *p, double bs[], int 
   const int on_tang = (bs[KID_B_LAT] > 89.) && g->d.grid_is_latlon;
   if (on_tang) {
     double xdot3, ydot3, xddot1, yddot1;
-    rotvec_to_tang(p, lonn, uvel3, vvel3, &xdot3, &ydot3);
-    rotvec_to_tang(p, lonn, ax1, ay1, &xddot1, &yddot1);
+    ko_rotvec_to_tang(p, lonn, uvel3, vvel3, &xdot3, &ydot3);
+    ko_rotvec_to_tang(p, lonn, ax1, ay1, &xddot1, &yddot1);
     double xdotn = xdot3 + (dt * xddot1), ydotn = ydot3 + (dt * yddot1);
-    rotvec_from_tang(p, lonn, xdotn, ydotn, &uveln, &vveln);
+    ko_rotvec_from_tang(p, lonn, xdotn, ydotn, &uveln, &vveln);
   } else { uveln = uvel3 + (dt * ax1); vveln = vvel3 + (dt * ay1); }
   if (p->override_iceberg_velocities) { uveln = p->u_override; vveln = p->v_override; }
   bs[KID_B_AXN] = axn; bs[KID_B_AYN] = ayn; bs[KID_B_BXN] = bxn; bs[KID_B_BYN] = byn;
@@ -677,16 +682,16 @@ static void verlet_step(const ko_grid *g, const kid_params *p, double bs[], int 
   {
     double lon1 = bs[KID_B_LON], lat1 = bs[KID_B_LAT], x1 = 0, y1 = 0;
     const int tang2 = (bs[KID_B_LAT] > 89.) && g->d.grid_is_latlon;
-    if (tang2) rotpos_to_tang(p, lon1, lat1, &x1, &y1);
-    double dxdl1, dydl; meters_to_grid(g, p, lat1, &dxdl1, &dydl);
+    if (tang2) ko_rotpos_to_tang(p, lon1, lat1, &x1, &y1);
+    double dxdl1, dydl; ko_meters_to_grid(g, p, lat1, &dxdl1, &dydl);
     double u1 = bs[KID_B_UVEL], v1 = bs[KID_B_VVEL];
     double uvel2 = u1 + (dt_2 * axn) + (dt_2 * bxn);
     double vvel2 = v1 + (dt_2 * ayn) + (dt_2 * byn);
     double xdot2 = 0, ydot2 = 0;
-    if (tang2) rotvec_to_tang(p, lon1, uvel2, vvel2, &xdot2, &ydot2);
+    if (tang2) ko_rotvec_to_tang(p, lon1, uvel2, vvel2, &xdot2, &ydot2);
     double u2 = uvel2 * dxdl1, v2 = vvel2 * dydl;
     double lo, la;
-    if (tang2) { double xn = x1 + (dt * xdot2), yn = y1 + (dt * ydot2); rotpos_from_tang(p, xn, yn, &lo, &la); }
+    if (tang2) { double xn = x1 + (dt * xdot2), yn = y1 + (dt * ydot2); ko_rotpos_from_tang(p, xn, yn, &lo, &la); }
     else { lo = lon1 + (dt * u2); la = lat1 + (dt * v2); }
     int bounced;
     ko_adjust_index_and_ground(g, p, &lo, &la, &i, &j, &xi, &yj, &bounced, err);

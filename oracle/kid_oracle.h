@@ -74,6 +74,14 @@ void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t
 /* reference traversal order: permutation sorted by (jne, ine, inorder-key) */
 void ko_reference_order(const kid_berg_soa *b, int64_t *perm);
 
+/* multiple time stepping / DEM (oracle/kid_oracle_mts.c) */
+void ko_evolve_icebergs_mts(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars);
+void ko_set_conglom_ids(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd);
+void ko_orig_bond_length(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd);
+double ko_quad_interp_depth(const ko_grid *g, const kid_params *p, double x, double y, int i, int j, double xi, double yj);
+void ko_run_step_mts(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
+                     double *acc, double *out, double *scalars);
+
 void ko_default_params(kid_params *p);
 int64_t ko_sizeof(int which);
 

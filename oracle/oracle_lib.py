@@ -137,6 +137,31 @@ class Oracle:
         s.id = bergs["id"].ctypes.data_as(C.POINTER(C.c_int64))
         return s
 
+    @staticmethod
+    def bond_soa(bonds, n):
+        s = T.BondSoA()
+        s.n, s.max_bonds = n, int(bonds["max_bonds"])
+        assert len(bonds["count"]) == n
+        s.count = bonds["count"].ctypes.data_as(C.POINTER(C.c_int32))
+        s.other_id = bonds["other_id"].ctypes.data_as(C.POINTER(C.c_int64))
+        s.broken = bonds["broken"].ctypes.data_as(C.POINTER(C.c_int32))
+        for k, name in enumerate(T.BOND_F64_NAMES):
+            a = bonds[name]
+            assert a.dtype == np.float64 and len(a) == s.max_bonds * n
+            s.f64[k] = _dp(a)
+        return s
+
+    def run_step_mts(self, bergs, bonds, nsteps=1):
+        """icebergs_run with mts=.true.; the first call after construction does the `Visited` block (IB:5409-5420)"""
+        s = self.soa(bergs)
+        bs = self.bond_soa(bonds, len(bergs["lon"]))
+        for _ in range(nsteps):
+            first = 0 if getattr(self, "_visited", False) else 1
+            self._visited = True
+            self.lib.ko_run_step_mts(C.byref(self.kg), C.byref(self.params), C.byref(s), C.byref(bs), first,
+                                     _dp(self.acc), _dp(self.out), _dp(self.scalars))
+        return bergs, bonds
+
     def step_local(self, bergs):
         s = self.soa(bergs)
         self.lib.ko_step_local(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]), _dp(self.acc), _dp(self.scalars))

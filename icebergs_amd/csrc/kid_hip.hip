@@ -19,6 +19,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "../../include/kid.h"
@@ -271,6 +272,8 @@ __global__ void __launch_bounds__(256) footloose_kernel(const DevGrid g, const k
   footloose_one(g, *pp, b, cx, q, acc, ncell, acc + (size_t)KID_NACC * ncell);
 }
 
+#include "kid_mts.inc"
+
 // -------------------------------------------------------------------------------------------------------
 // IB:6077-6150 sum_up_spread_fields + IB:3449-3488, per cell of the computational domain
 // -------------------------------------------------------------------------------------------------------
@@ -405,6 +408,11 @@ struct kid_handle {
   void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_perm_spare = nullptr;
   int resort_interval = 16, steps_since_sort = 0;
+  // multiple time stepping / DEM
+  MtsDev mts{}; MtsDev *d_mts = nullptr;
+  int mb = 0; bool mts_ready = false, mts_dirty = true, have_bonds = false, visited = false;
+  unsigned long long *d_key64[2] = {nullptr, nullptr}; int *d_rows[2] = {nullptr, nullptr};
+  void *d_mts_tmp = nullptr; size_t mts_tmp_bytes = 0;
   Flags flags{0, 0, 1, 0};
   bool have_static = false, have_forcing = false;
   bool profile = false;
@@ -440,8 +448,20 @@ static int nacc_active(const kid_handle *h) {
   return (h->params.diag_mask & diag_planes) ? KID_NACC : KID_NACC_CORE;
 }
 static int check_params(kid_handle *h, const kid_params *p) {
-  if (p->mts || p->dem) { h->err = "mts/dem (bonded DEM sub-stepping) is not implemented in this build"; return KID_EUNSUPPORTED; }
-  if (p->interactive_icebergs_on) { h->err = "interactive_icebergs_on is not implemented in this build"; return KID_EUNSUPPORTED; }
+  if (p->dem && !p->mts) { h->err = "dem needs mts=T (the DEM forces live on the MTS sub-steps)"; return KID_EINVAL; }
+  if (p->mts) {
+    if (p->Runge_not_Verlet) { h->err = "Runge_not_Verlet must be false to use MTS or DEM (FW:1485-1490)"; return KID_EINVAL; }
+    if (p->old_interp_flds_order) { h->err = "old_interp_flds_order is false whenever mts/dem is on (FW:1483)"; return KID_EINVAL; }
+    if (p->mts_sub_steps < 1) { h->err = "mts_sub_steps must be >= 1 (pass the value ice_bergs_framework_init derives, FW:1296-1301)"; return KID_EINVAL; }
+    if (p->dem && !p->explicit_inner_mts) { h->err = "dem forces explicit_inner_mts=T (FW:1433)"; return KID_EINVAL; }
+    if (p->dem && !p->iceberg_bonds_on) { h->err = "dem needs iceberg_bonds_on"; return KID_EINVAL; }
+    if (p->max_bonds < 1 || p->max_bonds > KID_MAX_BONDS) { h->err = "max_bonds out of range"; return KID_EINVAL; }
+    if (p->use_broken_bonds_for_substep_contact && !(p->break_bonds_on_sub_steps && p->dem && p->iceberg_bonds_on)) {
+      h->err = "use_broken_bonds_for_substep_contact requires break_bonds_on_sub_steps, dem and iceberg_bonds_on (FW:1438-1447)"; return KID_EINVAL; }
+    if (p->footloose) { h->err = "footloose together with mts is not implemented"; return KID_EUNSUPPORTED; }
+  } else if (p->interactive_icebergs_on || p->iceberg_bonds_on) {
+    h->err = "interacting / bonded bergs are implemented for the MTS scheme only (mts=T)"; return KID_EUNSUPPORTED;
+  }
   if (p->tidal_drift > 0.) { h->err = "tidal_drift needs FMS's random stream: not supported"; return KID_EUNSUPPORTED; }
   if (p->time_average_weight) { h->err = "time_average_weight is not implemented"; return KID_EUNSUPPORTED; }
   if (p->find_melt_using_spread_mass) { h->err = "find_melt_using_spread_mass is not implemented"; return KID_EUNSUPPORTED; }
@@ -511,6 +531,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   return KID_OK;
 }
 
+static void mts_free(kid_handle *h);
 int kid_destroy(kid_handle *h) {
   if (!h) return KID_EINVAL;
   (void)hipSetDevice(h->device);
@@ -538,6 +559,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_perm_spare) (void)hipFree(h->d_perm_spare);
   if (h->d_iceberg_counter) (void)hipFree(h->d_iceberg_counter);
   if (h->d_fl_cursor) (void)hipFree(h->d_fl_cursor);
+  mts_free(h);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
   if (h->d_redo_count) (void)hipFree(h->d_redo_count);
   for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
@@ -673,6 +695,7 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   h->flags.has_static = any_static ? 1 : 0;
   h->flags.has_fl = (any_fl || h->params.footloose) ? 1 : 0;
   h->n = host->n;
+  h->visited = false; h->have_bonds = false;
   KID_HIP(h, hipStreamSynchronize(h->stream));
   return KID_OK;
 }
@@ -865,11 +888,20 @@ static int launch_berg(kid_handle *h) {
 
 extern "C" {
 
-int kid_interp_gridded_fields_to_bergs(kid_handle *h) { if (!h) return KID_EINVAL; KID_HIP(h, hipSetDevice(h->device)); return launch_berg<PH_INTERP>(h); }
+static int mts_depth(kid_handle *h);
+int kid_evolve_icebergs_mts(kid_handle *h);
+int kid_interp_gridded_fields_to_bergs(kid_handle *h) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  int rc = launch_berg<PH_INTERP>(h);
+  if (rc || !h->params.mts) return rc;
+  return mts_depth(h);
+}
 int kid_evolve_icebergs(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
   if (h->params.static_icebergs) return KID_OK;  // IB:5428
+  if (h->params.mts) return kid_evolve_icebergs_mts(h);  // IB:5431
   return launch_berg<PH_EVOLVE>(h);
 }
 int kid_thermodynamics(kid_handle *h) {
@@ -941,12 +973,23 @@ int kid_create_gridded_icebergs_fields(kid_handle *h) {
   return launch_gather(h);
 }
 
+#include "kid_mts_host.inc"
+
 int kid_step_local(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
   int rc = kid_zero_accumulators(h);
   if (rc) return rc;
   const kid_params &p = h->params;
+  if (p.mts) {  // IB:5409-5512 with mts=T
+    if (!h->visited) { rc = mts_first_visit(h); if (rc) return rc; }
+    if (!p.static_icebergs) { rc = kid_evolve_icebergs_mts(h); if (rc) return rc; }
+    rc = kid_interp_gridded_fields_to_bergs(h);   // IB:5458
+    if (rc) return rc;
+    rc = kid_set_conglom_ids(h);                  // transfer_mts_bergs, IB:5459
+    if (rc) return rc;
+    return launch_berg<PH_THERMO | PH_SPREAD>(h);
+  }
   if (p.footloose) {  // calving sits between evolve and thermodynamics (IB:5453) and appends bergs: three launches
     rc = launch_berg<PH_INTERP | PH_EVOLVE>(h);
     if (rc) return rc;
@@ -979,7 +1022,7 @@ int kid_run_step(kid_handle *h, int nsteps) {
     if (rc) return rc;
     rc = kid_step_gather(h);
     if (rc) return rc;
-    if (h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised
+    if (!h->params.mts && h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised; bonded bergs keep their rows
       rc = kid_move_berg_between_cells(h);
       if (rc) return rc;
     }

@@ -97,6 +97,24 @@ module kid_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function kid_upload_bonds(h, soa) bind(C, name='kid_upload_bonds')
+      import :: c_int, c_ptr, kid_bond_soa
+      type(c_ptr), value :: h
+      type(kid_bond_soa), intent(in) :: soa
+    end function
+    integer(c_int) function kid_download_bonds(h, soa) bind(C, name='kid_download_bonds')
+      import :: c_int, c_ptr, kid_bond_soa
+      type(c_ptr), value :: h
+      type(kid_bond_soa), intent(inout) :: soa
+    end function
+    integer(c_int) function kid_evolve_icebergs_mts(h) bind(C, name='kid_evolve_icebergs_mts')   ! IB:5431
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_set_conglom_ids(h) bind(C, name='kid_set_conglom_ids')           ! IB:5459 / FW:2601
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
     integer(c_int) function kid_set_store_environment(h, on) bind(C, name='kid_set_store_environment')
       import :: c_int, c_ptr
       type(c_ptr), value :: h

@@ -108,6 +108,38 @@ class Icebergs:
         s = self._soa(bergs, bergs.get("_n"))
         self._check(self.lib.kid_upload_bergs(self.h, C.byref(s)), "kid_upload_bergs")
 
+    # ---- bonds (mts / dem) ----
+    @staticmethod
+    def _bond_soa(bonds, n):
+        s = T.BondSoA()
+        s.n, s.max_bonds = n, int(bonds["max_bonds"])
+        assert len(bonds["count"]) == n and bonds["count"].dtype == np.int32
+        s.count = bonds["count"].ctypes.data_as(C.POINTER(C.c_int32))
+        s.other_id = bonds["other_id"].ctypes.data_as(C.POINTER(C.c_int64))
+        s.broken = bonds["broken"].ctypes.data_as(C.POINTER(C.c_int32))
+        for k, name in enumerate(T.BOND_F64_NAMES):
+            a = bonds[name]
+            assert a.dtype == np.float64 and len(a) == s.max_bonds * n
+            s.f64[k] = _dp(a)
+        return s
+
+    def upload_bonds(self, bonds):
+        n, _ = self.num_bergs()
+        self._check(self.lib.kid_upload_bonds(self.h, C.byref(self._bond_soa(bonds, n))), "kid_upload_bonds")
+
+    def download_bonds(self, max_bonds):
+        from .synthetic import empty_bonds
+        n, _ = self.num_bergs()
+        bd = empty_bonds(n, max_bonds)
+        self._check(self.lib.kid_download_bonds(self.h, C.byref(self._bond_soa(bd, n))), "kid_download_bonds")
+        return bd
+
+    def set_conglom_ids(self):
+        self._check(self.lib.kid_set_conglom_ids(self.h), "kid_set_conglom_ids")
+
+    def evolve_icebergs_mts(self):
+        self._check(self.lib.kid_evolve_icebergs_mts(self.h), "kid_evolve_icebergs_mts")
+
     def num_bergs(self):
         a, b = C.c_int64(), C.c_int64()
         self._check(self.lib.kid_num_bergs(self.h, C.byref(a), C.byref(b)), "kid_num_bergs")

@@ -88,6 +88,19 @@ int kid_footloose_calving(kid_handle *h);
 int kid_thermodynamics(kid_handle *h);
 int kid_create_gridded_icebergs_fields(kid_handle *h);
 
+/* ---- bonded bergs, multiple time stepping, DEM (mts=T) ----
+ * Bond lists travel as kid_bond_soa (include/kid_types.h), uploaded after the bergs they belong to; rows of bond
+ * partners are re-derived from other_id (connect_all_bonds, FW:4963-5125).  While bonds exist the SoA is never
+ * re-binned, so rows are stable between upload and download.
+ *   kid_evolve_icebergs_mts   evolve_icebergs_mts IB:5431 / IB:6576-7078 (kid_evolve_icebergs dispatches to it when mts=T)
+ *   kid_set_conglom_ids       transfer_mts_bergs IB:5459 -> set_conglom_ids FW:2601-2646 with whole conglomerates resident
+ * kid_step_local / kid_run_step run the mts=T sequence of icebergs_run, including the once-after-upload `Visited`
+ * block (IB:5409-5420: interpolate, label conglomerates, orig_bond_length). */
+int kid_upload_bonds(kid_handle *h, const kid_bond_soa *host);
+int kid_download_bonds(kid_handle *h, kid_bond_soa *host);
+int kid_evolve_icebergs_mts(kid_handle *h);
+int kid_set_conglom_ids(kid_handle *h);
+
 /* grd%iceberg_counter_grd (FW:1017), the per-cell counter generate_id draws berg ids from; (isd:ied,jsd:jed) int32 */
 int kid_set_iceberg_counter(kid_handle *h, const int32_t *counter);
 int kid_get_iceberg_counter(kid_handle *h, int32_t *counter);

@@ -44,6 +44,77 @@ def run_hip(grid, params, bergs, nsteps, mode="fused", device=0):
         ib.close()
 
 
+def run_oracle_mts(grid, params, bergs, bonds, nsteps):
+    import oracle_lib
+    o = oracle_lib.Oracle(grid, params)
+    b, bd = S.copy_bergs(bergs), S.copy_bonds(bonds)
+    o.run_step_mts(b, bd, nsteps)
+    return (b, o.acc.copy(), o.out.copy(), o.scalars.copy()), bd
+
+
+def run_hip_mts(grid, params, bergs, bonds, nsteps, device=0):
+    from icebergs_amd.framework import Icebergs
+    ib = Icebergs(grid, params, capacity=max(len(bergs["lon"]), 1), device=device)
+    try:
+        ib.upload_bergs(bergs)
+        ib.upload_bonds(bonds)
+        ib.run(nsteps)
+        acc, out, scal = ib.fetch()
+        b = ib.download_bergs()
+        bd = ib.download_bonds(bonds["max_bonds"])
+        return (b, acc.copy(), out.copy(), scal.copy()), bd
+    finally:
+        ib.close()
+
+
+MTS_FIELDS = ["uvel_old", "vvel_old", "lon_old", "lat_old", "axn_fast", "ayn_fast", "bxn_fast", "byn_fast", "ang_vel", "ang_accel", "rot", "od"]
+BOND_STATE = ["length", "tangd1", "tangd2", "nstress", "sstress", "rel_rotation"]
+
+
+def bond_set(bergs, bonds, only_unbroken=False):
+    """{(id, other_id): slot}: the bonds as a set, independent of list order"""
+    n = len(bergs["lon"])
+    out = {}
+    for k in range(n):
+        for s in range(bonds["count"][k]):
+            if only_unbroken and bonds["broken"][s * n + k] != 0:
+                continue
+            out[(int(bergs["id"][k]), int(bonds["other_id"][s * n + k]))] = s * n + k
+    return out
+
+
+def compare_mts(ref, refbd, got, gotbd, label="", tol=1.0e-9):
+    """MTS/DEM: rows are stable (no re-binning), so bergs and bonds are compared row by row.  The set of bonds and the
+    set of broken bonds must be identical; states within `tol` (relative to the field max)."""
+    rb, gb = ref[0], got[0]
+    assert np.array_equal(rb["id"], gb["id"]) and np.array_equal(rb["alive"], gb["alive"]), label + ": rows differ"
+    for f in ("ine", "jne", "conglom_id", "n_bonds"):
+        assert np.array_equal(rb[f], gb[f]), "%s: %s differs" % (label, f)
+    rep = {}
+    for f in TRAJ_FIELDS + MTS_FIELDS + SIZE_FIELDS:
+        e = rel_err(gb[f], rb[f])
+        rep[f] = e
+        assert e <= tol, "%s: %s rel err %.3e > %.1e" % (label, f, e, tol)
+    assert np.array_equal(refbd["count"], gotbd["count"]), label + ": bond counts differ"
+    assert np.array_equal(refbd["other_id"], gotbd["other_id"]), label + ": bond partners differ"
+    assert np.array_equal(refbd["broken"], gotbd["broken"]), label + ": set of broken bonds differs"
+    for f in BOND_STATE + ["f_x", "f_y", "fd_x", "fd_y", "t", "t_d"]:
+        e = rel_err(gotbd[f], refbd[f])
+        rep["bond_" + f] = e
+        assert e <= tol, "%s: bond %s rel err %.3e > %.1e" % (label, f, e, tol)
+    for k in range(ref[1].shape[0]):
+        e = rel_err(got[1][k], ref[1][k])
+        assert e <= TOL_GRID, "%s: accumulator plane %d rel err %.3e" % (label, k, e)
+    for k in range(ref[2].shape[0]):
+        e = rel_err(got[2][k], ref[2][k])
+        assert e <= TOL_GRID, "%s: output plane %d rel err %.3e" % (label, k, e)
+    from icebergs_amd import types as T
+    for name in ("nbergs_melted", "nspeeding_tickets", "nbergs_alive", "error_count", "nbonds_broken"):
+        k = T.SCALAR_NAMES[name]
+        assert ref[3][k] == got[3][k], "%s: scalar %s %r != %r" % (label, name, got[3][k], ref[3][k])
+    return rep
+
+
 def compare(ref, got, label=""):
     rb, racc, rout, rscal = ref
     gb, gacc, gout, gscal = got

@@ -251,3 +251,23 @@ def test_store_environment_off(oracle):
             ib.set_store_environment(False)
     finally:
         ib.close()
+
+
+@pytest.mark.parametrize("case", ["hex_free", "hex_grounded", "square_free", "two_bergs", "thickness_jitter"])
+def test_c4_mts_dem(oracle, case):
+    """BASELINE config 4 family at oracle size: bonded DEM elements under MTS velocity Verlet (200 explicit sub-steps
+    per step), grounding on a seamount with stress fracture, square and hexagonal packing, a collision between two
+    conglomerates, and elements of unequal thickness (where the side that evaluates a bond pair matters)."""
+    kw = {"hex_free": dict(bump=(150e3, 150e3)), "hex_grounded": dict(),
+          "square_free": dict(bump=(150e3, 150e3), hexagonal=False, nx=6, ny=6),
+          "two_bergs": dict(bump=(150e3, 150e3), two_bergs=True, hexagonal=False, nx=4, ny=6),
+          "thickness_jitter": dict(bump=(150e3, 150e3), thickness_jitter=0.2)}[case]
+    grid, p, b, bd = S.config_c4(**kw)
+    S.set_diag_all(p)
+    nsteps = 6
+    ref, refbd = P.run_oracle_mts(grid, p, b, bd, nsteps)
+    got, gotbd = P.run_hip_mts(grid, p, b, bd, nsteps)
+    rep = P.compare_mts(ref, refbd, got, gotbd, "C4/" + case)
+    print(case, {k: "%.1e" % v for k, v in rep.items() if v > 0})
+    if case in ("hex_grounded", "two_bergs"):
+        assert (refbd["broken"] != 0).sum() > 0  # the case does fracture

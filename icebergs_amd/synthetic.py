@@ -321,9 +321,11 @@ def bond_neighbours(b, n, reach, max_bonds=6):
     bd = empty_bonds(len(b["lon"]), max_bonds)
     N = len(b["lon"])
     x, y = b["lon"][:n], b["lat"][:n]
+    from scipy.spatial import cKDTree
+    tree = cKDTree(np.column_stack([x, y]))
+    pairs = tree.query_ball_point(np.column_stack([x, y]), reach * (1.0 - 1e-12))
     for k in range(n):
-        d2 = (x - x[k]) ** 2 + (y - y[k]) ** 2
-        near = np.nonzero((d2 < reach * reach) & (np.arange(n) != k))[0]
+        near = np.array(sorted(o for o in pairs[k] if o != k), dtype=np.int64)
         assert len(near) <= max_bonds, (k, len(near))
         for s, o in enumerate(near):
             bd["other_id"][s * N + k] = b["id"][o]
@@ -333,7 +335,7 @@ def bond_neighbours(b, n, reach, max_bonds=6):
 
 
 def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45, nj=45, gridres=5000.0, sub_steps=200,
-              bump=(58.0e3, 60.0e3), bump_depth=50.0, origin=(44.0e3, 35.0e3), frac=(1850.0, 1000.0), thickness_jitter=0.0,
+              bump=(58.0e3, 60.0e3), bump_depth=50.0, origin=(44137.0, 35211.0), frac=(1850.0, 1000.0), thickness_jitter=0.0,
               seed=4, two_bergs=False):
     """BASELINE config 4 family: a tabular berg made of bonded DEM elements (hexagonal or square packing) drifting at
     0.1 m/s onto a Gaussian seamount on the Cartesian grid of tests/dem_ground_frac_test (driver DRV:288-307,

@@ -55,3 +55,11 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".F90", ".f90", ".c", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not banned.search(text), os.path.join(dirpath, f)
+
+
+def test_structs_have_no_implicit_padding():
+    """Fortran stream I/O and bind(C) derived types move components one by one: every pad must be spelled out"""
+    import ctypes
+    from icebergs_amd import types as T
+    for cls in (T.Params, T.GridDesc, T.BergSoA, T.BondSoA):
+        assert ctypes.sizeof(cls) == sum(ctypes.sizeof(t) for _, t in cls._fields_), cls.__name__

@@ -96,9 +96,9 @@ def test_fortran_driver_config2(oracle, tmp_path):
 def test_fortran_driver_reports_errors(tmp_path):
     """A bad request must abort with the library's message (the reference's FATAL convention), not continue."""
     grid, p, b = S.config_c1()
-    p.mts = 1  # not implemented in this build -> KID_EUNSUPPORTED from kid_create
+    p.tidal_drift = 1.0  # needs FMS's random stream -> KID_EUNSUPPORTED from kid_create
     case, res = str(tmp_path / "case.bin"), str(tmp_path / "res.bin")
     write_case(case, grid, p, b, 1, 0)
     r = subprocess.run([REPLAY, case, res], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert "mts/dem" in (r.stderr + r.stdout)
+    assert "tidal_drift" in (r.stderr + r.stdout)

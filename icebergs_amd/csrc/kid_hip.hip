@@ -15,6 +15,7 @@
 //   gather_kernel              : per cell, the 9-point gather of sum_up_spread_fields (IB:6126-6138) + ustar.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 #include <string>
@@ -413,6 +414,9 @@ struct kid_handle {
   int mb = 0; bool mts_ready = false, mts_dirty = true, have_bonds = false, visited = false;
   unsigned long long *d_key64[2] = {nullptr, nullptr}; int *d_rows[2] = {nullptr, nullptr};
   void *d_mts_tmp = nullptr; size_t mts_tmp_bytes = 0;
+  hipGraphExec_t sub_graph_exec = nullptr;  // the captured sub-step loop of evolve_icebergs_mts
+  long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
+  bool use_graph = true;
   Flags flags{0, 0, 1, 0};
   bool have_static = false, have_forcing = false;
   bool profile = false;
@@ -499,6 +503,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   if (rc) return rc;
   h->params = *params;
   h->capacity = capacity;
+  if (getenv("KID_MTS_NO_GRAPH")) h->use_graph = false;  // A/B switch for measurements
   KID_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   for (int k = 0; k < KID_NGRID_STATIC; ++k) { KID_HIP(h, hipMalloc(&h->d_static[k], h->ncell * sizeof(double))); KID_HIP(h, hipMemset(h->d_static[k], 0, h->ncell * sizeof(double))); }
@@ -528,6 +533,10 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_redo_count, sizeof(int)));
   KID_HIP(h, hipEventCreate(&h->ev0)); KID_HIP(h, hipEventCreate(&h->ev1));
   KID_HIP(h, hipEventCreate(&h->ev2)); KID_HIP(h, hipEventCreate(&h->ev3));
+  // The hipMemset calls above run on the null stream and are asynchronous to the host, while all later work goes to a
+  // non-blocking stream that does not order itself behind the null stream: without this wait a zero-fill could land
+  // after the first upload (seen once as a zeroed `ine` array of a 1-berg population).
+  KID_HIP(h, hipDeviceSynchronize());
   return KID_OK;
 }
 

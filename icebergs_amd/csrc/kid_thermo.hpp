@@ -25,8 +25,12 @@ namespace kid {
 // That is ~14x fewer atomics and, unlike a shuffle scan, costs about one LDS write + one LDS read per value.
 constexpr int KID_MAXRUN = 16;  // the hot build shares at most this many cell packets per wave
 constexpr int KID_CHUNK = 12;  // staged values per flush: 6 KB of LDS per wave
+// row stride of the staging block: 64 would put lane r of every row q on the same LDS bank (measured: half of the LDS
+// cycles of the spreading phase were bank conflicts); 66 doubles shifts each row by 4 banks and leaves 2 doubles of
+// slack behind a row for the unrolled, predicated reads of seg_flush_impl
+constexpr int KID_ROW = 66;
 struct Seg {
-  lds_double *val;   // [KID_CHUNK][64] staging, this wave
+  lds_double *val;   // [KID_CHUNK][KID_ROW] staging, this wave
   lds_int *head;     // [64] first lane of run r
   lds_int *len;      // [64] length of run r
   lds_int *cell;     // [64] cell index of run r (<0: inactive lanes, nothing to add)
@@ -37,7 +41,7 @@ struct Seg {
   int npend;         // staged slots (wave-uniform)
 };
 // LDS a workgroup of 4 waves needs for its Seg tables
-constexpr int KID_SEG_LDS_DOUBLES = 4 * KID_CHUNK * 64;
+constexpr int KID_SEG_LDS_DOUBLES = 4 * KID_CHUNK * KID_ROW + 4;
 constexpr int KID_SEG_LDS_INTS = 4 * (3 * 64 + KID_CHUNK);
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -48,7 +52,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *ints) {
   Seg s;
   const int lane = (int)__lane_id(), wave = (int)(threadIdx.x >> 6);
-  s.val = vals + wave * (KID_CHUNK * 64);
+  s.val = vals + wave * (KID_CHUNK * KID_ROW);
   lds_int *base = ints + wave * (3 * 64 + KID_CHUNK);
   s.head = base; s.len = base + 64; s.cell = base + 128; s.plane = base + 192;
   const int prev = __shfl_up(key, 1);
@@ -76,7 +80,18 @@ __device__ __noinline__ void seg_flush_impl(lds_double *val, lds_int *head, lds_
     const int q = (int)(((unsigned)item * M) >> 16), r = item - q * R;
     const int h = head[r], n = len[r], c = cell[r];
     double sum = 0.;
-    for (int t = 0; t < n; ++t) sum += val[q * 64 + h + t];
+    const lds_double *v = val + q * KID_ROW + h;
+    int t = 0;
+    for (; t + 4 <= n; t += 4) {  // four reads in flight; the adds stay in lane order
+      const double a0 = v[t], a1 = v[t + 1], a2 = v[t + 2], a3 = v[t + 3];
+      sum += a0; sum += a1; sum += a2; sum += a3;
+    }
+    {
+      const double a0 = v[t], a1 = v[t + 1], a2 = v[t + 2];  // reads past the run stay inside the staging block
+      if (t < n) sum += a0;
+      if (t + 1 < n) sum += a1;
+      if (t + 2 < n) sum += a2;
+    }
     if (c >= 0 && sum != 0.) unsafeAtomicAdd(acc + (size_t)plane[q] * ncell + (size_t)c, sum);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -92,7 +107,7 @@ __device__ __forceinline__ void cell_add(double *acc, size_t ncell, int plane, i
   if (active && v == 1.2345e-300) acc[(size_t)plane * ncell + c] = v;
   return;
 #endif
-  s.val[s.npend * 64 + (int)__lane_id()] = active ? v : 0.0;
+  s.val[s.npend * KID_ROW + (int)__lane_id()] = active ? v : 0.0;
   s.plane[s.npend] = plane;
   s.npend += 1;
   if (s.npend == KID_CHUNK) seg_flush(s, acc, ncell);

@@ -246,7 +246,7 @@ def config_c2(n=1_000_000, seed=2, continents=False):
     return grid, p, b
 
 
-def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3, dt=600.0):
+def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3, dt=600.0, spread=False):
     """BASELINE config 3, the footloose profile of tests/footloose_tests/input.nml: Cartesian 1 km grid, Verlet,
     footloose calving into FL bits (or child bergs), 300 m thick tabular bergs with +-20 % jitter, ocean 1 m/s east,
     wind stress -1 (about -25.8 m/s as a wind), SST -0.5.  The arrays carry spare rows for children (b["_n"] live).
@@ -275,11 +275,14 @@ def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3
     p.apply_thickness_cutoff_to_gridded_melt, p.apply_thickness_cutoff_to_bergs_melt, p.melt_cutoff = 1, 1, 10.0
     p.old_interp_flds_order = 0
     rng = np.random.default_rng(seed)
-    cap = max(capacity_factor * n, n + 64)
+    cap = int(max(capacity_factor * n, n + 64))
     b = empty_bergs(cap)
     b["alive"][n:] = 0
     d = grid["desc"]
-    i = rng.integers(d.isc + 3, d.isc + max(4, (d.iec - d.isc) // 3), size=n).astype(np.int32)  # western third: they drift east
+    if spread:  # throughput runs: the whole interior, in reference (cell) order
+        i = rng.integers(d.isc + 3, d.iec - 2, size=n).astype(np.int32)
+    else:
+        i = rng.integers(d.isc + 3, d.isc + max(4, (d.iec - d.isc) // 3), size=n).astype(np.int32)  # western third: they drift east
     j = rng.integers(d.jsc + 4, d.jec - 3, size=n).astype(np.int32)
     xi, yj = rng.uniform(0.05, 0.95, n), rng.uniform(0.05, 0.95, n)
     b["ine"][:n], b["jne"][:n], b["xi"][:n], b["yj"][:n] = i, j, xi, yj
@@ -303,6 +306,11 @@ def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3
     b["uvel"][:n] = 0.5
     b["uvel_old"][:n] = 0.5
     b["_n"] = n
+    if spread:
+        o = np.lexsort((b["ine"][:n], b["jne"][:n]))
+        for k, v in b.items():
+            if hasattr(v, "dtype"):
+                v[:n] = v[:n][o]
     return grid, p, b
 
 

@@ -26,7 +26,7 @@ def build():
 
 
 def load():
-    so = os.path.join(_HERE, "libkid_oracle.so")
+    so = os.environ.get("KID_ORACLE_SO") or os.path.join(_HERE, "libkid_oracle.so")  # KID_ORACLE_SO: e.g. a sanitizer build
     if not os.path.exists(so):
         build()
     lib = C.CDLL(so)

@@ -172,8 +172,11 @@ def compare(ref, got, label=""):
 
     def G(f):
         return gb[f][ga][org]
-    assert np.array_equal(R("ine"), G("ine")), label + ": ine differs"
-    assert np.array_equal(R("jne"), G("jne")), label + ": jne differs"
+    def where(f):
+        bad = np.nonzero(R(f) != G(f))[0][:4]
+        return "%s: %s differs at %s: ref %s got %s (lon ref %s got %s)" % (label, f, bad, R(f)[bad], G(f)[bad], R("lon")[bad], G("lon")[bad])
+    assert np.array_equal(R("ine"), G("ine")), where("ine")
+    assert np.array_equal(R("jne"), G("jne")), where("jne")
     for f in TRAJ_FIELDS:
         e = rel_err(G(f), R(f))
         report[f] = e

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bergs", type=int, default=1_000_000, help="bergs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce + gather on the critical path")
+    ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)
     args = ap.parse_args()
@@ -69,33 +71,50 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
+        if args.force_collective and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     # ---- workload: config 2, one shard of `bergs` per rank, replicated grid ----
     # weak scaling: every rank generates its own shard of the 8e7-class population (seed differs per rank)
     grid, params, bergs = S.config_c2(n=args.bergs, seed=2 + 1000 * rank)
     ib = Icebergs(grid, params, capacity=args.bergs, device=local_rank)
-    ib.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit stream for the kernels, the torch copies and (N>1) the RCCL collectives that order themselves
+    # against torch's current stream
+    main_stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(main_stream)
+    ib.set_stream(main_stream.cuda_stream)
     ib.upload_bergs(bergs)
     ib.set_store_environment(False)  # config 2 runs with ignore_traj=T: nobody reads berg%uo..hi (see include/kid.h)
     # forcing planes resident on the device (as an ocean/ice model on the same GPU would hand them over)
     forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
     forcing_ptrs = [t.data_ptr() for t in forcing_dev]
-    # accumulator block in a torch tensor so that RCCL can reduce it in place
+    # accumulator block(s) in torch tensors so that RCCL can reduce them in place
+    from icebergs_amd.distributed import ShardedStepper, PipelinedStepper, accumulator_views
     _, count = ib.accum_device_ptr()
-    acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
-    ib.bind_accum_buffer(acc_t.data_ptr(), count)
-    from icebergs_amd.distributed import ShardedStepper
-    stepper = ShardedStepper(ib, acc_t, ib.ncell, params.diag_mask, dist)
-    ncore = T.ENUMS["KID_NACC_CORE"] * ib.ncell
+    multi = world > 1 or args.force_collective
+    if multi and not args.no_pipeline:
+        # N>1: the all-reduce + gather of step k run on a second stream under the kernels of step k+1
+        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective)
+        nreduced = stepper.views[0][0].numel()
 
-    def step():
-        ib.set_forcing_device(forcing_ptrs)      # forcing prepass: per-cell records built on the device
-        stepper.step()                           # fused per-berg kernels; RCCL all-reduce (N>1); 9-point gather
+        def step():
+            stepper.set_forcing_device(forcing_ptrs)
+            stepper.step()
+    else:
+        acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
+        ib.bind_accum_buffer(acc_t.data_ptr(), count)
+        stepper = ShardedStepper(ib, acc_t, ib.ncell, params.diag_mask, dist, params=params, force_collective=args.force_collective)
+        nreduced = stepper.planes.numel()
+
+        def step():
+            ib.set_forcing_device(forcing_ptrs)      # forcing prepass: per-cell records built on the device
+            stepper.step()                           # fused per-berg kernels; RCCL all-reduce (N>1); 9-point gather
 
     def fence():
+        stepper.flush()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -141,7 +160,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
                                    "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s, ignore_traj=T" % args.bergs,
                        "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
-                       "exchange": "RCCL all-reduce of %d per-cell planes (%.1f MB) per step" % (T.ENUMS["KID_NACC_CORE"], ncore * 8 / 1e6) if world > 1 else "none (1 GPU)",
+                       "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, "" if args.no_pipeline else ", overlapped with the next step's kernels")) if multi else "none (1 GPU)",
                        "bergs_alive_at_end": n_alive},
             "per_gpu_value": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -592,7 +592,9 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
 }
 int kid_set_stream(kid_handle *h, void *s) {
   if (!h) return KID_EINVAL;
-  h->stream = s ? (hipStream_t)s : h->own_stream;
+  // NULL is the device's default (null) stream -- e.g. torch's default current stream -- not "no stream": work the
+  // caller orders with its own events or collectives must really be on the stream it names
+  h->stream = (hipStream_t)s;
   return KID_OK;
 }
 int kid_sync(kid_handle *h) {

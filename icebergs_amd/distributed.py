@@ -25,13 +25,30 @@ def take_shard(bergs, rank, world):
     return {k: np.ascontiguousarray(v[lo:hi]) for k, v in bergs.items()}
 
 
-def accumulator_views(acc_block, ncell, diag_mask=0):
+def needs_footprint_planes(params):
+    """True if the gather reads area/Uvel/Vvel_on_ocean (27 of the 46 always-zeroed planes): spread_area feeds the
+    thickness cut-off of the gridded melt (IB:3477-3488) and ustar (IB:3466), spread_u/vvel feed ustar and the
+    fields passed to the ocean model (IB:3419-3433); otherwise only mass_on_ocean is summed (IB:3406)."""
+    if params is None:
+        return True
+    E = T.ENUMS
+    diag = E["KID_DIAG_SPREAD_UVEL"] | E["KID_DIAG_SPREAD_VVEL"] | E["KID_DIAG_SPREAD_AREA"] | E["KID_DIAG_USTAR_ICEBERG"]
+    return bool(params.pass_fields_to_ocean_model or (params.diag_mask & diag) or
+                (params.apply_thickness_cutoff_to_gridded_melt and params.melt_cutoff >= 0.0))
+
+
+def accumulator_views(acc_block, ncell, diag_mask=0, params=None):
     """(planes that must be reduced, scalar increments) as views of the contiguous accumulator block."""
     diag_planes = sum(T.ENUMS[k] for k in (
         "KID_DIAG_MELT_BY_CLASS", "KID_DIAG_FL_PARENT_MELT", "KID_DIAG_FL_CHILD_MELT", "KID_DIAG_MELT_BUOY",
         "KID_DIAG_MELT_EROS", "KID_DIAG_MELT_CONV", "KID_DIAG_MELT_BUOY_FL", "KID_DIAG_MELT_EROS_FL",
         "KID_DIAG_MELT_CONV_FL", "KID_DIAG_VIRTUAL_AREA", "KID_DIAG_MASS", "KID_DIAG_U_ICEBERG", "KID_DIAG_V_ICEBERG"))
-    nplanes = T.NACC if (diag_mask & diag_planes) else T.ENUMS["KID_NACC_CORE"]
+    if diag_mask & diag_planes:
+        nplanes = T.NACC
+    elif needs_footprint_planes(params):
+        nplanes = T.ENUMS["KID_NACC_CORE"]
+    else:
+        nplanes = T.ENUMS["KID_A_MASS_ON_OCEAN"] + 9   # melt/heat/bits planes + the 9 mass_on_ocean slots
     return acc_block[: nplanes * ncell], acc_block[T.NACC * ncell: T.NACC * ncell + T.NSCALAR]
 
 
@@ -41,12 +58,12 @@ class ShardedStepper:
     `backend` is anything with step_local() / step_gather() that accumulates into `acc_block` (a torch tensor:
     device memory bound to the HIP handle in production, host memory in the gloo tests)."""
 
-    def __init__(self, backend, acc_block, ncell, diag_mask=0, dist=None, resort_interval=16):
+    def __init__(self, backend, acc_block, ncell, diag_mask=0, dist=None, resort_interval=16, params=None, force_collective=False):
         self.backend = backend
         self.resort_interval = resort_interval
         self._since_sort = 0
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
-        self.planes, self.scalars = accumulator_views(acc_block, ncell, diag_mask)
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
+        self.planes, self.scalars = accumulator_views(acc_block, ncell, diag_mask, params)
 
     def step(self):
         self.backend.step_local()
@@ -58,3 +75,66 @@ class ShardedStepper:
         if self.resort_interval and self._since_sort >= self.resort_interval and hasattr(self.backend, "move_berg_between_cells"):
             self.backend.move_berg_between_cells()  # icebergs.F90:5437, amortised over `resort_interval` steps
             self._since_sort = 0
+
+
+    def flush(self):
+        pass
+
+
+class PipelinedStepper:
+    """ShardedStepper for the HIP handle with the exchange taken off the critical path.
+
+    The per-berg kernels of step k+1 do not read what the all-reduce and the 9-point gather of step k produce (those
+    feed the host model, not the bergs), so the handle alternates between two accumulator blocks: step k scatters into
+    block k%2 on the compute stream; a second stream waits for it, all-reduces the block over RCCL and runs the gather
+    while the compute stream is already zeroing and filling the other block.  `flush()` joins both streams; outputs
+    (kid_get_accumulators) are those of the last flushed step."""
+
+    def __init__(self, ib, params, dist=None, resort_interval=16, force_collective=False):
+        import torch
+        self.torch, self.ib, self.params = torch, ib, params
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
+        self.dev = torch.device("cuda", ib.device)
+        _, self.count = ib.accum_device_ptr()
+        self.acc = [torch.zeros(self.count, dtype=torch.float64, device=self.dev) for _ in range(2)]
+        self.views = [accumulator_views(a, ib.ncell, params.diag_mask, params) for a in self.acc]
+        self.compute = torch.cuda.current_stream(self.dev)
+        self.comm = torch.cuda.Stream(self.dev)
+        self.local_done = [torch.cuda.Event() for _ in range(2)]
+        self.gather_done = [torch.cuda.Event() for _ in range(2)]
+        self.gather_reads_forcing = needs_footprint_planes(params)   # ustar reads the ocean velocity records
+        self.resort_interval, self._since_sort, self.k = resort_interval, 0, 0
+
+    def set_forcing_device(self, ptrs):
+        if self.gather_reads_forcing and self.k >= 1:   # the previous gather may still be reading the old records
+            self.compute.wait_event(self.gather_done[(self.k - 1) & 1])
+        self.ib.set_stream(self.compute.cuda_stream)
+        self.ib.set_forcing_device(ptrs)
+
+    def step(self):
+        torch, ib, cur = self.torch, self.ib, self.k & 1
+        if self.k >= 2:
+            self.compute.wait_event(self.gather_done[cur])   # block `cur` was last read by the gather of step k-2
+        ib.bind_accum_buffer(self.acc[cur].data_ptr(), self.count)
+        ib.set_stream(self.compute.cuda_stream)
+        ib.step_local()
+        self.local_done[cur].record(self.compute)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.local_done[cur])
+            if self.dist is not None:
+                planes, scalars = self.views[cur]
+                self.dist.all_reduce(planes)
+                self.dist.all_reduce(scalars)
+            ib.set_stream(self.comm.cuda_stream)
+            ib.step_gather()
+            self.gather_done[cur].record(self.comm)
+        ib.set_stream(self.compute.cuda_stream)
+        self._since_sort += 1
+        if self.resort_interval and self._since_sort >= self.resort_interval:
+            ib.move_berg_between_cells()
+            self._since_sort = 0
+        self.k += 1
+
+    def flush(self):
+        self.comm.synchronize()
+        self.compute.synchronize()

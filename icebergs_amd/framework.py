@@ -25,6 +25,7 @@ class Icebergs:
         self.lib = _lib.load()
         self.grid = grid
         self.params = params
+        self.device = int(device)
         d = grid["desc"]
         self.ni, self.nj = d.ied - d.isd + 1, d.jed - d.jsd + 1
         self.ncell = self.ni * self.nj

@@ -50,7 +50,8 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
                kid_handle **out);
 int kid_destroy(kid_handle *h);
 int kid_set_params(kid_handle *h, const kid_params *params);
-/* Launch on an existing hipStream_t (e.g. PyTorch's current stream); NULL = the handle's own stream. */
+/* Launch on an existing hipStream_t (e.g. PyTorch's current stream).  NULL names the device's default (null) stream;
+ * a handle that is never given a stream uses a private non-blocking one. */
 int kid_set_stream(kid_handle *h, void *hip_stream);
 int kid_sync(kid_handle *h);
 const char *kid_last_error(const kid_handle *h);

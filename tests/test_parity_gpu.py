@@ -271,3 +271,44 @@ def test_c4_mts_dem(oracle, case):
     print(case, {k: "%.1e" % v for k, v in rep.items() if v > 0})
     if case in ("hex_grounded", "two_bergs"):
         assert (refbd["broken"] != 0).sum() > 0  # the case does fracture
+
+
+def test_pipelined_stepper_matches_plain(oracle):
+    """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)
+    must give what the plain sequence gives; run here on one GPU, with and without a (world-size-1) RCCL all-reduce."""
+    import torch
+    from icebergs_amd.framework import Icebergs
+    from icebergs_amd.distributed import ShardedStepper, PipelinedStepper
+    from icebergs_amd import types as T
+    grid, p, b = S.config_c2(n=30000, seed=21, continents=True)
+    nsteps = 37
+    dev = torch.device("cuda", 0)
+    forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
+    ptrs = [t.data_ptr() for t in forcing_dev]
+
+    def run(kind):
+        ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
+        try:
+            ib.set_stream(torch.cuda.current_stream().cuda_stream)
+            ib.upload_bergs(b)
+            if kind == "plain":
+                _, count = ib.accum_device_ptr()
+                acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
+                ib.bind_accum_buffer(acc_t.data_ptr(), count)
+                st = ShardedStepper(ib, acc_t, ib.ncell, p.diag_mask, None, params=p)
+                for _ in range(nsteps):
+                    ib.set_forcing_device(ptrs)
+                    st.step()
+            else:
+                st = PipelinedStepper(ib, p, None)
+                for _ in range(nsteps):
+                    st.set_forcing_device(ptrs)
+                    st.step()
+            st.flush()
+            torch.cuda.synchronize()
+            acc, out, scal = ib.fetch()
+            return ib.download_bergs(), acc.copy(), out.copy(), scal.copy()
+        finally:
+            ib.close()
+    ref, got = run("plain"), run("pipelined")
+    P.compare(ref, got, "pipelined vs plain")

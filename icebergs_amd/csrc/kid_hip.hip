@@ -39,7 +39,7 @@ struct BergPtrs {
   int32_t *i[KID_NB_I32];
   int64_t *id;
 };
-struct Flags { int has_static, has_fl, store_env, pad; };
+struct Flags { int has_static, has_fl, store_env, footprint; };  // footprint: area/Uvel/Vvel_on_ocean are read by somebody
 
 // -------------------------------------------------------------------------------------------------------
 // grid prepass kernels
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
     if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
       const bool act2 = t.alive && !skipped;
       if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
-        spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg);
+        spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg, fl.footprint != 0);
       berg_diagnostics(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
     seg_flush(seg, acc, ncell);
@@ -445,11 +445,19 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.ssh = h->d_forcing[KID_F_SSH];
   return g;
 }
+// area/Uvel/Vvel_on_ocean (27 planes) are intermediates of spread_area / spread_uvel / spread_vvel / ustar_iceberg
+// (IB:3419-3474), which the reference evaluates only for `id_*>0` or pass_fields_to_ocean_model: when nobody reads them
+// they are neither scattered nor zeroed nor exchanged (the reference fills them regardless and drops them)
+static bool footprint_needed(const kid_params &p) {
+  const int diag = KID_DIAG_SPREAD_UVEL | KID_DIAG_SPREAD_VVEL | KID_DIAG_SPREAD_AREA | KID_DIAG_USTAR_ICEBERG;
+  return p.pass_fields_to_ocean_model || (p.diag_mask & diag);
+}
 static int nacc_active(const kid_handle *h) {
   const int diag_planes = KID_DIAG_MELT_BY_CLASS | KID_DIAG_FL_PARENT_MELT | KID_DIAG_FL_CHILD_MELT | KID_DIAG_MELT_BUOY |
                           KID_DIAG_MELT_EROS | KID_DIAG_MELT_CONV | KID_DIAG_MELT_BUOY_FL | KID_DIAG_MELT_EROS_FL |
                           KID_DIAG_MELT_CONV_FL | KID_DIAG_VIRTUAL_AREA | KID_DIAG_MASS | KID_DIAG_U_ICEBERG | KID_DIAG_V_ICEBERG;
-  return (h->params.diag_mask & diag_planes) ? KID_NACC : KID_NACC_CORE;
+  if (h->params.diag_mask & diag_planes) return KID_NACC;
+  return footprint_needed(h->params) ? KID_NACC_CORE : KID_A_MASS_ON_OCEAN + 9;
 }
 static int check_params(kid_handle *h, const kid_params *p) {
   if (p->dem && !p->mts) { h->err = "dem needs mts=T (the DEM forces live on the MTS sub-steps)"; return KID_EINVAL; }
@@ -502,6 +510,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   int rc = check_params(h, params);
   if (rc) return rc;
   h->params = *params;
+  h->flags.footprint = footprint_needed(h->params) ? 1 : 0;
   h->capacity = capacity;
   if (getenv("KID_MTS_NO_GRAPH")) h->use_graph = false;  // A/B switch for measurements
   KID_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -587,6 +596,7 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   if (rc) return rc;
   h->params = *params;
   h->tables_dirty = true;
+  h->flags.footprint = footprint_needed(h->params) ? 1 : 0;
   if (!h->params.old_interp_flds_order) h->flags.store_env = 1;  // the stored environment is an input again
   return KID_OK;
 }

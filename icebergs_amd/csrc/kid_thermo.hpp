@@ -444,7 +444,7 @@ __device__ __noinline__ void hexagon_into_quadrants(const kid_params &p, double 
 // ---------------------------------------------------------------------------------------------------------
 template <class CELL>
 __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
-                                            int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg) {
+                                            int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg, bool footprint) {
   constexpr double rho_sw = 1035.;  // IB:3919 shadows the module's 1025
   const int c = g.idx(i, j);
   const double a_ij = cellv.area();
@@ -504,8 +504,11 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
     if (__ballot(ok && w[s] != 0.) == 0ull) continue;  // slot unused by the whole wave
+    cell_add(acc, ncell, base[0] + s, c, w[s] * vars[0] * Ifu, seg, ok);
+    if (footprint) {  // wave-uniform: area / Uvel / Vvel footprints only when something downstream reads them
 #pragma unroll
-    for (int v = 0; v < 4; ++v) cell_add(acc, ncell, base[v] + s, c, w[s] * vars[v] * Ifu, seg, ok);
+      for (int v = 1; v < 4; ++v) cell_add(acc, ncell, base[v] + s, c, w[s] * vars[v] * Ifu, seg, ok);
+    }
   }
 }
 

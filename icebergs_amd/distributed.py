@@ -26,15 +26,14 @@ def take_shard(bergs, rank, world):
 
 
 def needs_footprint_planes(params):
-    """True if the gather reads area/Uvel/Vvel_on_ocean (27 of the 46 always-zeroed planes): spread_area feeds the
-    thickness cut-off of the gridded melt (IB:3477-3488) and ustar (IB:3466), spread_u/vvel feed ustar and the
-    fields passed to the ocean model (IB:3419-3433); otherwise only mass_on_ocean is summed (IB:3406)."""
+    """True if the gather reads area/Uvel/Vvel_on_ocean (27 of the 46 core planes): spread_area / spread_uvel /
+    spread_vvel / ustar_iceberg exist only for `id_*>0` or pass_fields_to_ocean_model (IB:3419-3474); otherwise only
+    mass_on_ocean is summed (IB:3406) and the library neither scatters, zeroes nor exchanges those 27 planes."""
     if params is None:
         return True
     E = T.ENUMS
     diag = E["KID_DIAG_SPREAD_UVEL"] | E["KID_DIAG_SPREAD_VVEL"] | E["KID_DIAG_SPREAD_AREA"] | E["KID_DIAG_USTAR_ICEBERG"]
-    return bool(params.pass_fields_to_ocean_model or (params.diag_mask & diag) or
-                (params.apply_thickness_cutoff_to_gridded_melt and params.melt_cutoff >= 0.0))
+    return bool(params.pass_fields_to_ocean_model or (params.diag_mask & diag))   # = footprint_needed() in kid_hip.hip
 
 
 def accumulator_views(acc_block, ncell, diag_mask=0, params=None):

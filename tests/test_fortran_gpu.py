@@ -75,7 +75,7 @@ def test_fortran_driver_config1(oracle, tmp_path, mode):
     assert r.returncode == 0, r.stderr + r.stdout
     got = read_result(res, grid)
     ref = P.run_oracle(grid, p, b, nsteps)
-    P.compare(ref, got, "fortran/C1/mode%d" % mode)
+    P.compare(ref, got, "fortran/C1/mode%d" % mode, params=p)
 
 
 @pytest.mark.gpu
@@ -89,7 +89,7 @@ def test_fortran_driver_config2(oracle, tmp_path):
     assert r.returncode == 0, r.stderr + r.stdout
     got = read_result(res, grid)
     ref = P.run_oracle(grid, p, b, 6)
-    P.compare(ref, got, "fortran/C2")
+    P.compare(ref, got, "fortran/C2", params=p)
 
 
 @pytest.mark.gpu

@@ -24,7 +24,7 @@ def test_c1_rk4_defaults(oracle, mode):
     grid, p, b = S.config_c1()
     S.set_diag_all(p)
     ref, got = _both(grid, p, b, 144, mode)
-    rep = P.compare(ref, got, "C1/rk4/" + mode)
+    rep = P.compare(ref, got, "C1/rk4/" + mode, params=p)
     assert ref[0]["alive"].sum() >= 6  # most bergs stay on the 20x20 domain
     print({k: v for k, v in rep.items() if k in ("lon", "lat", "uvel", "mass")})
 
@@ -37,7 +37,7 @@ def test_c1_verlet_newbilin(oracle, mode):
     p.old_bug_bilin = 0
     S.set_diag_all(p)
     ref, got = _both(grid, p, b, 144, mode)
-    P.compare(ref, got, "C1/verlet/" + mode)
+    P.compare(ref, got, "C1/verlet/" + mode, params=p)
 
 
 def test_c1_verlet_new_interp_order(oracle):
@@ -50,7 +50,7 @@ def test_c1_verlet_new_interp_order(oracle):
     p.use_new_predictive_corrective = 1
     for mode in ("fused", "phases"):
         ref, got = _both(grid, p, b, 60, mode)
-        P.compare(ref, got, "C1/verlet-neworder/" + mode)
+        P.compare(ref, got, "C1/verlet-neworder/" + mode, params=p)
 
 
 @pytest.mark.parametrize("continents", [False, True])
@@ -59,7 +59,7 @@ def test_c2_latlon(oracle, continents):
     rectangular mass spreading; `continents` adds land rectangles so that bergs bounce off coasts."""
     grid, p, b = S.config_c2(n=40000, seed=2, continents=continents)
     ref, got = _both(grid, p, b, 12, "fused")
-    P.compare(ref, got, "C2/continents=%s" % continents)
+    P.compare(ref, got, "C2/continents=%s" % continents, params=p)
 
 
 def test_c2_phases_equals_fused(oracle):
@@ -81,7 +81,7 @@ def test_c2_bergy_bits_and_rolling_schemes(oracle):
     p.speed_limit = 0.05
     S.set_diag_all(p)
     ref, got = _both(grid, p, b, 8, "fused")
-    P.compare(ref, got, "C2/bergy-bits")
+    P.compare(ref, got, "C2/bergy-bits", params=p)
     assert ref[3][1] >= 0  # counters compared exactly inside compare()
 
 
@@ -97,7 +97,7 @@ def test_melting_to_death_and_compaction(oracle):
     p.dt = 86400.0
     ref = P.run_oracle(grid, p, b, 10)
     got = P.run_hip(grid, p, b, 10, mode="fused")
-    P.compare(ref, got, "melt-to-death")
+    P.compare(ref, got, "melt-to-death", params=p)
     assert ref[3][1] > 0, "the test must actually melt some bergs"
     ib = Icebergs(grid, p, capacity=len(b["lon"]))
     ib.set_resort_interval(0)
@@ -120,7 +120,7 @@ def test_empty_and_ragged_populations(oracle):
     for n in (1, 63, 65, 257):
         grid, p, b = S.config_c2(n=n, seed=100 + n)
         ref, got = _both(grid, p, b, 3, "fused")
-        P.compare(ref, got, "ragged n=%d" % n)
+        P.compare(ref, got, "ragged n=%d" % n, params=p)
     grid, p, b = S.config_c2(n=1, seed=3)
     ib = Icebergs(grid, p, capacity=8)
     e = S.empty_bergs(0)
@@ -136,7 +136,7 @@ def test_hexagonal_spreading(oracle):
     p.hexagonal_icebergs = 1
     p.initial_orientation = 10.0
     ref, got = _both(grid, p, b, 3, "fused")
-    P.compare(ref, got, "hexagonal")
+    P.compare(ref, got, "hexagonal", params=p)
 
 
 def test_move_berg_between_cells(oracle):
@@ -156,7 +156,7 @@ def test_move_berg_between_cells(oracle):
         ib.run(6)
         acc, out, scal = ib.fetch()
         got = (ib.download_bergs(), acc.copy(), out.copy(), scal.copy())
-        P.compare(ref, got, "resort interval %d" % interval)
+        P.compare(ref, got, "resort interval %d" % interval, params=p)
         res.append(got)
         if interval == 1:
             gb = got[0]
@@ -182,7 +182,7 @@ def test_c3_footloose(oracle, style, mode):
     grid, p, b = S.config_c3(n=400, seed=3, fl_style=style)
     S.set_diag_all(p)
     ref, got = _both(grid, p, b, 40, mode)
-    P.compare(ref, got, "C3/%s/%s" % (style, mode))
+    P.compare(ref, got, "C3/%s/%s" % (style, mode), params=p)
     from icebergs_amd import types as T
     ncalved = ref[3][T.SCALAR_NAMES["nbergs_calved_fl"]]
     assert ncalved >= 5, ncalved
@@ -311,4 +311,4 @@ def test_pipelined_stepper_matches_plain(oracle):
         finally:
             ib.close()
     ref, got = run("plain"), run("pipelined")
-    P.compare(ref, got, "pipelined vs plain")
+    P.compare(ref, got, "pipelined vs plain", params=p)

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Regenerates the regression vectors in this directory from the CPU oracle (oracle/kid_oracle*.c).
+
+These are NOT reference outputs (the reference cannot be built in this image): they freeze what the
+oracle produced when the parity tests were green, so that a later edit of the oracle (or of the synthetic generators)
+that changes results is noticed by `pytest -m "not gpu"`, and so that the GPU tests have fixed vectors to hit as well.
+One .npz per case: the inputs are rebuilt from the named generator + seed (icebergs_amd/synthetic.py), the file holds
+the expected berg state, the scalars and the non-zero accumulator/output planes after `nsteps` steps.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from icebergs_amd import synthetic as S  # noqa: E402
+
+BERG_FIELDS = ["lon", "lat", "uvel", "vvel", "axn", "ayn", "bxn", "byn", "xi", "yj", "mass", "thickness", "width", "length",
+               "mass_of_bits", "mass_scaling", "mass_of_fl_bits", "mass_of_fl_bergy_bits", "fl_k", "ine", "jne", "alive", "id"]
+
+
+def cases():
+    """name -> (builder, nsteps); builder returns (grid, params, bergs[, bonds])"""
+    def c1_rk4():
+        g, p, b = S.config_c1(); S.set_diag_all(p); return g, p, b
+
+    def c1_verlet():
+        g, p, b = S.config_c1(); p.Runge_not_Verlet = 0; p.old_bug_bilin = 0; S.set_diag_all(p); return g, p, b
+
+    def c2_small():
+        g, p, b = S.config_c2(n=600, seed=2, continents=True); S.set_diag_all(p); return g, p, b
+
+    def c3_fl_bits():
+        g, p, b = S.config_c3(n=200, seed=3, fl_style="fl_bits"); S.set_diag_all(p); return g, p, b
+
+    def c3_new_bergs():
+        g, p, b = S.config_c3(n=200, seed=3, fl_style="new_bergs"); S.set_diag_all(p); return g, p, b
+
+    def c4_hex_grounded():
+        g, p, b, bd = S.config_c4(); S.set_diag_all(p); return g, p, b, bd
+
+    def c4_two_bergs():
+        g, p, b, bd = S.config_c4(bump=(150e3, 150e3), two_bergs=True, hexagonal=False, nx=4, ny=6); S.set_diag_all(p); return g, p, b, bd
+    return {"c1_rk4": (c1_rk4, 144), "c1_verlet": (c1_verlet, 144), "c2_small": (c2_small, 8), "c3_fl_bits": (c3_fl_bits, 40),
+            "c3_new_bergs": (c3_new_bergs, 40), "c4_hex_grounded": (c4_hex_grounded, 4), "c4_two_bergs": (c4_two_bergs, 6)}
+
+
+def run_case(name):
+    import parity as P
+    build, nsteps = cases()[name]
+    made = build()
+    if len(made) == 4:
+        grid, p, b, bd = made
+        (rb, acc, out, scal), rbd = P.run_oracle_mts(grid, p, b, bd, nsteps)
+    else:
+        grid, p, b = made
+        rb, acc, out, scal = P.run_oracle(grid, p, b, nsteps)
+        rbd = None
+    n = int(rb.get("_n", len(rb["lon"])))
+    res = {"nsteps": np.int64(nsteps), "n": np.int64(n), "scalars": scal}
+    for f in BERG_FIELDS:
+        res["b_" + f] = rb[f][:n]
+    live = [k for k in range(acc.shape[0]) if acc[k].any()]
+    res["acc_planes"] = np.array(live, dtype=np.int64)
+    res["acc"] = acc[live]
+    res["out"] = out
+    if rbd is not None:
+        res["bond_count"] = rbd["count"]
+        res["bond_broken"] = rbd["broken"]
+        res["bond_other_id"] = rbd["other_id"]
+        for f in ("rot", "ang_vel", "conglom_id", "n_bonds"):
+            res["b_" + f] = rb[f][:n]
+    return res
+
+
+def main():
+    for name in cases():
+        res = run_case(name)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **res)
+        print("wrote %s (%d bergs, %d steps, %.1f KB)" % (path, int(res["n"]), int(res["nsteps"]), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+"""Golden vectors (tests/golden/): the reference's own known-answer data, and frozen oracle outputs.
+
+* reference_known_answers.json -- inputs and expected outputs of the reference's self tests (hexagon_test,
+  point_in_triangle_test, basal_melt_test); the oracle must reproduce them (this is what pins the oracle).
+* <case>.npz -- what the oracle produced for the named synthetic case when the parity suite was green
+  (tests/golden/make_golden.py regenerates them).  CPU: the oracle must still produce them.  GPU: the HIP library must
+  hit them through the C ABI, without the oracle in the loop.
+"""
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as G  # noqa: E402
+import parity as P  # noqa: E402
+
+from icebergs_amd import synthetic as S  # noqa: E402
+from icebergs_amd import types as T  # noqa: E402
+
+KNOWN = json.load(open(os.path.join(HERE, "golden", "reference_known_answers.json")))
+CASES = sorted(G.cases())
+
+
+def test_reference_known_answers(oracle):
+    k = KNOWN["basal_melt_test"]
+    p, d, i = S.default_params(), T.GridDesc(), KNOWN["basal_melt_test"]["inputs"]
+    d.grid_is_latlon = 1
+    for three, key in ((0, "two_equation_melt"), (1, "three_equation_melt")):
+        v = oracle.ko_find_basal_melt(C.byref(d), C.byref(p), i["dvo"], i["lat"], i["salt"], i["temp"], three, i["thickness"])
+        assert v == pytest.approx(k[key], rel=k["rel_tol"])
+    k = KNOWN["point_in_triangle_test"]
+    (ax, ay), (bx, by), (cx, cy) = k["triangle"]
+    assert bool(oracle.ko_point_in_triangle(ax, ay, bx, by, cx, cy, *k["point"])) == k["inside"]
+    k = KNOWN["hexagon_test"]
+    H = 1.0
+    Sd = 2.0 * H / math.sqrt(3.0)
+    A_expect = (3.0 * math.sqrt(3.0) / 2.0) * Sd * Sd
+    for case in k["cases"]:
+        out = [C.c_double() for _ in range(5)]
+        oracle.ko_hexagon_into_quadrants(case["x0_in_S"] * Sd, case["y0_in_H"] * H, H, 0.0, *[C.byref(o) for o in out])
+        A, Q = out[0].value, [o.value for o in out[1:]]
+        assert abs(A - A_expect) <= k["tol"], case["name"]
+        for q, frac in zip(Q, case["Q_over_A"]):
+            assert abs(q - frac * A) <= k["tol"], case["name"]
+
+
+def _check(name, res, tol_state, tol_grid, exact_ints=True, stiff=False):
+    gold = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    # survivors only (the library drops dead rows when it re-bins).  Footloose children of one cell born in one step may
+    # swap counter values between the two sides: group them by the cell part of the id and order by where they are.
+    def order(d):
+        idx = np.nonzero(d["b_alive"] != 0)[0]
+        ident = d["b_id"][idx]
+        primary = np.where(ident >= (1 << 32), (ident & 0xFFFFFFFF) + (1 << 40), ident)
+        return idx[np.lexsort((d["b_mass_scaling"][idx], d["b_lat"][idx], d["b_lon"][idx], primary))]
+    og, orr = order(gold), order(res)
+    assert len(og) == len(orr), "survivors"
+    assert np.array_equal(np.sort(gold["b_id"][og]), np.sort(res["b_id"][orr]))
+    for f in G.BERG_FIELDS:
+        a, b = res["b_" + f][orr], gold["b_" + f][og]
+        if f in ("ine", "jne"):
+            assert np.array_equal(a, b), f
+        elif f in ("id", "alive"):
+            continue
+        else:
+            t = tol_state
+            if stiff and f in ("axn", "ayn", "bxn", "byn"):
+                t = 1e-4
+            assert P.rel_err(a.astype(float), b.astype(float)) <= t, (name, f, P.rel_err(a.astype(float), b.astype(float)))
+    planes = {int(k): gold["acc"][q] for q, k in enumerate(gold["acc_planes"])}
+    got = {int(k): res["acc"][q] for q, k in enumerate(res["acc_planes"])}
+    full = np.zeros((T.NACC,) + gold["out"].shape[1:])
+    for k, v in planes.items():
+        full[k] = v
+    sc = P.acc_scales(full)
+    for k, v in planes.items():
+        g = got.get(k, np.zeros_like(v))
+        e = float(np.max(np.abs(g - v))) / sc[k] if sc[k] > 0 else float(np.max(np.abs(g)))
+        assert e <= tol_grid, (name, "acc plane", k, e)
+    solid = np.abs(gold["out"][T.OUT_NAMES["spread_area"]]) > 1.0e-9
+    for k in range(gold["out"].shape[0]):
+        a, b = (res["out"][k][solid], gold["out"][k][solid]) if k == T.OUT_NAMES["ustar_iceberg"] else (res["out"][k], gold["out"][k])
+        assert P.rel_err(a, b) <= tol_grid, (name, "out plane", k)
+    for sname in ("nbergs_melted", "nbergs_calved_fl", "nspeeding_tickets", "nbergs_alive", "error_count", "nbonds_broken"):
+        k = T.SCALAR_NAMES[sname]
+        assert res["scalars"][k] == gold["scalars"][k], (name, sname)
+    if "bond_count" in gold.files:
+        assert np.array_equal(res["bond_count"], gold["bond_count"]), "bond lists"
+        n = len(gold["bond_count"])
+        live = (np.arange(len(gold["bond_broken"]) // n)[:, None] < gold["bond_count"][None, :]).ravel()
+        assert np.array_equal(res["bond_broken"][live], gold["bond_broken"][live]), "broken bonds"
+        assert np.array_equal(res["bond_other_id"][live], gold["bond_other_id"][live]), "bond partners"
+        assert np.array_equal(res["b_conglom_id"], gold["b_conglom_id"]) and np.array_equal(res["b_n_bonds"], gold["b_n_bonds"])
+        assert P.rel_err(res["b_rot"], gold["b_rot"]) <= 1e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(oracle, name):
+    """same code, same machine class: the oracle must give back its frozen outputs (tight tolerance, libm only)"""
+    _check(name, G.run_case(name), 1e-12, 1e-12)
+
+
+def _run_hip_case(name):
+    from icebergs_amd.framework import Icebergs
+    build, nsteps = G.cases()[name]
+    made = build()
+    grid, p, b = made[:3]
+    ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
+    try:
+        ib.upload_bergs(b)
+        if len(made) == 4:
+            ib.upload_bonds(made[3])
+        ib.run(nsteps)
+        acc, out, scal = ib.fetch()
+        rb = ib.download_bergs()
+        n = len(rb["lon"])
+        res = {"nsteps": nsteps, "n": n, "scalars": scal.copy(), "out": out.copy()}
+        for f in G.BERG_FIELDS:
+            res["b_" + f] = rb[f]
+        live = [k for k in range(acc.shape[0]) if acc[k].any()]
+        res["acc_planes"], res["acc"] = np.array(live, dtype=np.int64), acc[live].copy()
+        if len(made) == 4:
+            bd = ib.download_bonds(made[3]["max_bonds"])
+            res.update(bond_count=bd["count"], bond_broken=bd["broken"], bond_other_id=bd["other_id"])
+            for f in ("rot", "ang_vel", "conglom_id", "n_bonds"):
+                res["b_" + f] = rb[f]
+        return res
+    finally:
+        ib.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_hits_golden(name):
+    """the HIP library against the frozen vectors, no oracle in the loop"""
+    res = _run_hip_case(name)
+    gold = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    mts = name.startswith("c4")
+    _check_hip(name, res, gold, mts)
+
+
+def _check_hip(name, res, gold, mts):
+    # the library drops dead rows when it re-bins (every 16 steps): compare survivors only
+    tol = 1e-9 if mts else P.TOL_TRAJ
+    alive_gold = int((gold["b_alive"] != 0).sum())
+    assert int((res["b_alive"] != 0).sum()) == alive_gold
+    _check(name, res, tol, 10 * P.TOL_GRID if mts else P.TOL_GRID, stiff=mts)

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
   const bool inrange = tid < total;
   const long long k = inrange ? (FAST ? tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
-  const bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
+  bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
   if (__ballot(was_alive) == 0ull) continue;  // wave-uniform; every other lane stays to the end (wave-level sums below)
   double *scal = acc + (size_t)KID_NACC * ncell;
 
@@ -123,15 +123,23 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
   Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);
   const lds_double *pk = nullptr;
   if (FAST) {
-    if (seg.R > KID_MAXRUN) {  // an unsorted wave: no packet sharing to be had, the general build takes all of it
-      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; }
-      continue;
-    }
     lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (KID_MAXRUN * PK_STRIDE);
     const int lane = (int)__lane_id();
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int myrun = __popcll(seg.heads & le) - 1;
+    // There are packets for KID_MAXRUN distinct cells per wave.  As the cell order decays between two re-binnings a
+    // wave collects out-of-place bergs, each a run of its own: the lanes of the runs beyond the KID_MAXRUN-th go to the
+    // general build one by one (handing over the whole wave made 15 % of the population take the slow path by the end
+    // of a 16-step interval).
+    if (myrun >= KID_MAXRUN) {
+      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; }
+      was_alive = false;
+    }
+    if (__ballot(was_alive) == 0ull) continue;
+    const int nstage = seg.R < KID_MAXRUN ? seg.R : KID_MAXRUN;
     // lane q fetches packet elements q and q+64 of every distinct cell: where they live is fixed per lane
     const PacketSrc s0 = packet_source(g, lane), s1 = packet_source(g, (lane < PK_SIZE - 64) ? 64 + lane : 0);
-    for (int r = 0; r < seg.R; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
+    for (int r = 0; r < nstage; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
       const int c = seg.cell[r];
       if (c >= 0) {
         wpk[r * PK_STRIDE + lane] = *reinterpret_cast<const double *>(s0.base + (long long)c * s0.stride);
@@ -139,8 +147,7 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    pk = wpk + (__popcll(seg.heads & le) - 1) * PK_STRIDE;
+    pk = wpk + (myrun < KID_MAXRUN ? myrun : 0) * PK_STRIDE;
   }
   d.xi = b.f[KID_B_XI][kk]; d.yj = b.f[KID_B_YJ][kk];
   d.lon = b.f[KID_B_LON][kk]; d.lat = b.f[KID_B_LAT][kk];
@@ -1080,6 +1087,15 @@ int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count) {
   return KID_OK;
 }
 
+int kid_last_redo_count(kid_handle *h, int64_t *count) {
+  if (!h || !count) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  int c = 0;
+  KID_HIP(h, hipMemcpyAsync(&c, h->d_redo_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  *count = c;
+  return KID_OK;
+}
 int kid_profile_enable(kid_handle *h, int on) {
   if (!h) return KID_EINVAL;
   h->profile = on != 0;

@@ -97,6 +97,11 @@ module kid_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function kid_last_redo_count(h, count) bind(C, name='kid_last_redo_count')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: count
+    end function
     integer(c_int) function kid_upload_bonds(h, soa) bind(C, name='kid_upload_bonds')
       import :: c_int, c_ptr, kid_bond_soa
       type(c_ptr), value :: h

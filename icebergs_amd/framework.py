@@ -218,6 +218,11 @@ class Icebergs:
     def bind_accum_buffer(self, ptr, count):
         self._check(self.lib.kid_bind_accum_buffer(self.h, C.c_void_p(ptr), int(count)), "kid_bind_accum_buffer")
 
+    def last_redo_count(self):
+        c = C.c_int64()
+        self._check(self.lib.kid_last_redo_count(self.h, C.byref(c)), "kid_last_redo_count")
+        return c.value
+
     def profile(self, on=True):
         self._check(self.lib.kid_profile_enable(self.h, 1 if on else 0), "kid_profile_enable")
 

@@ -122,6 +122,8 @@ int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count);
 
 /* ---- measurement: HIP-event timing of the per-berg kernel on the launch stream ---- */
 int kid_profile_enable(kid_handle *h, int on);
+/* telemetry: bergs that the hot build handed to the general build in the most recent per-berg launch */
+int kid_last_redo_count(kid_handle *h, int64_t *count);
 int kid_profile_get(kid_handle *h, double *berg_kernel_ms_total, int64_t *berg_kernel_launches,
                     double *all_ms_total);
 

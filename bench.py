@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bergs", type=int, default=1_000_000, help="bergs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce + gather on the critical path")
+    ap.add_argument("--no-pipeline", action="store_true", help="keep the general build, the all-reduce and the gather on the critical path")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)
@@ -95,8 +95,9 @@ def main():
     from icebergs_amd.distributed import ShardedStepper, PipelinedStepper, accumulator_views
     _, count = ib.accum_device_ptr()
     multi = world > 1 or args.force_collective
-    if multi and not args.no_pipeline:
-        # N>1: the all-reduce + gather of step k run on a second stream under the kernels of step k+1
+    if not args.no_pipeline:
+        # the general build of each half-population, the all-reduce (N>1) and the gather of step k run on a second
+        # stream under the hot-build kernels of the other half / of step k+1
         stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective)
         nreduced = stepper.views[0][0].numel()
 
@@ -127,6 +128,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_submit = time.perf_counter() - t0   # host time to enqueue the steps (diagnostic: is the host the bottleneck?)
     fence()
     elapsed = time.perf_counter() - t0
     berg_ms, launches, _ = ib.profile_get()
@@ -162,7 +164,7 @@ def main():
                        "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
                        "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, "" if args.no_pipeline else ", overlapped with the next step's kernels")) if multi else "none (1 GPU)",
                        "bergs_alive_at_end": n_alive},
-            "per_gpu_value": value / world,
+            "per_gpu_value": value / world, "host_submit_ms_per_step": 1e3 * t_submit / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "berg_kernel<true, true, 14u, true> (RK4, old interp order, evolve|thermo|spread, hot build)",
                          "kernel_ms_avg": kern_ms, "kernel_launches": launches,

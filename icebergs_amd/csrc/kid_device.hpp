@@ -454,7 +454,7 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
 // ---------------------------------------------------------------------------------------------------------
 // IB:7819-8063 adjust_index_and_ground (debug=.false.)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __noinline__ void adjust_index_slow(const DevGrid &g, const kid_params &p, double &lon, double &lat,
+__device__ __forceinline__ void adjust_index_slow(const DevGrid &g, const kid_params &p, double &lon, double &lat,
                                               int &i, int &j, double &xi, double &yj, int &err) {
   // cold path: hop cells / bounce off land.  (The second pos_within_cell(i0,j0) of IB:7940 repeats the caller's.)
   constexpr double posn_eps = 0.05;

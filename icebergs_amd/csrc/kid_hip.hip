@@ -54,9 +54,18 @@ __global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec 
   geo[c] = r;
 }
 
-__global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec *vel, TrcRec *trc, int ni, int nj) {
+// Optional extras fused into the per-cell prepass (kid_step_prepare): keep a copy of the ssh plane, zero the cell's
+// entries of the first `zero_planes` accumulator planes, zero two redo counters -- one launch instead of five.
+struct PrepExtras { double *ssh_copy; double *acc; int zero_planes; int *cnt0, *cnt1; };
+__global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec *vel, TrcRec *trc, int ni, int nj, PrepExtras ex) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ni * nj) return;
+  if (ex.ssh_copy) ex.ssh_copy[c] = gp.fo[KID_F_SSH][c];
+  if (ex.acc) {
+    const size_t ncell = (size_t)ni * (size_t)nj;
+    for (int q = 0; q < ex.zero_planes; ++q) ex.acc[(size_t)q * ncell + (size_t)c] = 0.;
+  }
+  if (c == 0) { if (ex.cnt0) *ex.cnt0 = 0; if (ex.cnt1) *ex.cnt1 = 0; }
   const int il = c % ni, jl = c / ni;
   VelRec v;
   v.cosr = gp.st[KID_G_COS][c]; v.sinr = gp.st[KID_G_SIN][c];
@@ -93,9 +102,17 @@ __global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec
 //                A berg that meets anything else is left untouched and its index is appended to `redo`.
 //   FAST=false : the general code (cell hops, coast bounce, polar cells, tangent plane) over the `redo` list.
 // Keeping the rare branches out of the hot build roughly halves its register footprint (2 waves/SIMD, no scratch).
-struct Redo { int *list; int *count; };
+#ifndef KID_GENERAL_WAVES_PER_EU
+#define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
+#endif
+struct Redo { int *list; int *count; long long k0, klen; };   // k0, klen: the rows the hot build covers in this launch
+#ifdef KID_EXP_NUM_VGPR
+#define KID_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(KID_EXP_NUM_VGPR)))
+#else
+#define KID_NUM_VGPR_ATTR
+#endif
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST>
-__global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(const DevGrid g, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
+__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid g, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
                                                    double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
   // The parameter block (142 dwords) and the 51 field pointers are read through device-memory tables on demand:
   // as by-value kernel arguments they were all pinned in SGPRs, overflowed the scalar file and came back as
@@ -107,11 +124,11 @@ __global__ void __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : 1) berg_kernel(
   __shared__ int lds_ints[KID_SEG_LDS_INTS];                         // run tables of the 4 waves
   __shared__ double lds_pk[FAST ? 4 * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the 4 waves (hot build)
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
-  const long long total = FAST ? n : (long long)(*redo.count);
+  const long long total = FAST ? redo.klen : (long long)(*redo.count);
   for (long long tid = (long long)blockIdx.x * 256ll + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * 256ll + threadIdx.x) : (tid - threadIdx.x < total));
        tid += (long long)gridDim.x * 256ll) {
   const bool inrange = tid < total;
-  const long long k = inrange ? (FAST ? tid : (long long)redo.list[tid]) : 0ll;
+  const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
   bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
   if (__ballot(was_alive) == 0ull) continue;  // wave-uniform; every other lane stays to the end (wave-level sums below)
@@ -410,6 +427,13 @@ struct kid_handle {
   double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
   unsigned long long *d_count = nullptr;
   int *d_redo_list = nullptr, *d_redo_count = nullptr;  // bergs the FAST build hands to the general build
+  // pipelined launches (kid_set_side_stream): the population goes through the hot build in two halves on the main
+  // stream while the general build of each half runs on the side stream, under the hot build of the other half
+  hipStream_t side_stream = nullptr; bool pipelined = false;
+  int *d_redo_list2 = nullptr, *d_redo_count2 = nullptr;
+  int *d_redo_cnt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [part][parity]: a step's counters are zeroed by its prepass
+  int redo_parity = 0; bool redo_prezeroed = false, acc_prezeroed = false;
+  hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   int *d_fl_cursor = nullptr;
   unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
@@ -547,6 +571,11 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_fl_cursor, sizeof(int)));
   KID_HIP(h, hipMalloc(&h->d_redo_list, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipMalloc(&h->d_redo_count, sizeof(int)));
+  KID_HIP(h, hipMalloc(&h->d_redo_list2, (size_t)capacity * sizeof(int)));
+  KID_HIP(h, hipMalloc(&h->d_redo_count2, 4 * sizeof(int)));
+  KID_HIP(h, hipMemset(h->d_redo_count2, 0, 4 * sizeof(int)));
+  for (int part = 0; part < 2; ++part) for (int par = 0; par < 2; ++par) h->d_redo_cnt[part][par] = h->d_redo_count2 + (2 * part + par);
+  for (int q = 0; q < 2; ++q) { KID_HIP(h, hipEventCreateWithFlags(&h->evF[q], hipEventDisableTiming)); KID_HIP(h, hipEventCreateWithFlags(&h->evG[q], hipEventDisableTiming)); }
   KID_HIP(h, hipEventCreate(&h->ev0)); KID_HIP(h, hipEventCreate(&h->ev1));
   KID_HIP(h, hipEventCreate(&h->ev2)); KID_HIP(h, hipEventCreate(&h->ev3));
   // The hipMemset calls above run on the null stream and are asynchronous to the host, while all later work goes to a
@@ -587,6 +616,9 @@ int kid_destroy(kid_handle *h) {
   mts_free(h);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
   if (h->d_redo_count) (void)hipFree(h->d_redo_count);
+  if (h->d_redo_list2) (void)hipFree(h->d_redo_list2);
+  if (h->d_redo_count2) (void)hipFree(h->d_redo_count2);
+  for (int q = 0; q < 2; ++q) { if (h->evF[q]) (void)hipEventDestroy(h->evF[q]); if (h->evG[q]) (void)hipEventDestroy(h->evG[q]); }
   for (auto &pe : h->pending) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -607,6 +639,23 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   if (!h->params.old_interp_flds_order) h->flags.store_env = 1;  // the stored environment is an input again
   return KID_OK;
 }
+// order the main stream behind general-build launches that are still in flight on the side stream
+static int join_side(kid_handle *h) {
+  for (int q = 0; q < 2; ++q)
+    if (h->evG_live[q]) { KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[q], 0)); }
+  return KID_OK;
+}
+int kid_set_side_stream(kid_handle *h, void *s, int enable) {
+  if (!h) return KID_EINVAL;
+  KID_HIP(h, hipSetDevice(h->device));
+  int rc = join_side(h);
+  if (rc) return rc;
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  h->evG_live[0] = h->evG_live[1] = false;
+  h->side_stream = (hipStream_t)s;
+  h->pipelined = enable != 0;
+  return KID_OK;
+}
 int kid_set_stream(kid_handle *h, void *s) {
   if (!h) return KID_EINVAL;
   // NULL is the device's default (null) stream -- e.g. torch's default current stream -- not "no stream": work the
@@ -617,6 +666,7 @@ int kid_set_stream(kid_handle *h, void *s) {
 int kid_sync(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   KID_HIP(h, hipStreamSynchronize(h->stream));
   return KID_OK;
 }
@@ -631,12 +681,12 @@ static int pack_static(kid_handle *h) {
   return KID_OK;
 }
 // src[k]: where forcing plane k currently lives on the device (the handle's own copy, or the caller's buffer)
-static int pack_forcing(kid_handle *h, const double *const src[KID_NFORCING]) {
+static int pack_forcing(kid_handle *h, const double *const src[KID_NFORCING], const PrepExtras ex = PrepExtras{nullptr, nullptr, 0, nullptr, nullptr}) {
   GridPlanes gp;
   for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
   for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = src[k] ? src[k] : h->d_forcing[k];
   const int nb = (int)((h->ncell + 255) / 256);
-  hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_vel, h->d_trc, h->ni, h->nj);
+  hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_vel, h->d_trc, h->ni, h->nj, ex);
   KID_HIP(h, hipGetLastError());
   return KID_OK;
 }
@@ -686,10 +736,31 @@ int kid_set_forcing_device(kid_handle *h, const double *const fields[KID_NFORCIN
   return pack_forcing(h, fields);
 }
 
+// kid_set_forcing_device + kid_zero_accumulators (+ the reset of this step's redo counters) as ONE per-cell launch
+int kid_step_prepare(kid_handle *h, const double *const fields[KID_NFORCING]) {
+  if (!h) return KID_EINVAL;
+  if (!h->have_static) { h->err = "kid_set_static_grid must be called first"; return KID_EINVAL; }
+  if (!fields && !h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
+  KID_HIP(h, hipSetDevice(h->device));
+  const double *none[KID_NFORCING] = {};
+  const double *const *src = fields ? fields : none;
+  h->redo_parity ^= 1;
+  PrepExtras ex;
+  ex.ssh_copy = (src[KID_F_SSH] && src[KID_F_SSH] != h->d_forcing[KID_F_SSH]) ? h->d_forcing[KID_F_SSH] : nullptr;
+  ex.acc = h->d_acc; ex.zero_planes = nacc_active(h);
+  ex.cnt0 = h->d_redo_cnt[0][h->redo_parity]; ex.cnt1 = h->d_redo_cnt[1][h->redo_parity];
+  h->have_forcing = true;
+  const int rc = pack_forcing(h, src, ex);
+  if (rc) return rc;
+  h->acc_prezeroed = true; h->redo_prezeroed = true;
+  return KID_OK;
+}
+
 int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   if (!h || !host || host->n < 0) return KID_EINVAL;
   if (host->n > h->capacity) { h->err = "more bergs than capacity"; return KID_ECAPACITY; }
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   const size_t n = (size_t)host->n;
   bool any_static = false, any_fl = false;
   for (int f = 0; f < KID_NB_F64; ++f) {
@@ -732,6 +803,7 @@ int kid_download_bergs(kid_handle *h, kid_berg_soa *host) {
   if (!h || !host) return KID_EINVAL;
   if (host->n < h->n) { h->err = "host SoA too small"; return KID_EINVAL; }
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   const size_t n = (size_t)h->n;
   for (int f = 0; f < KID_NB_F64; ++f)
     if (host->f64[f]) KID_HIP(h, hipMemcpyAsync(host->f64[f], h->bp.f[f], n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -746,6 +818,7 @@ int kid_download_bergs(kid_handle *h, kid_berg_soa *host) {
 int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   if (n_slots) *n_slots = h->n;
   if (n_alive) {
     unsigned long long cnt = 0;
@@ -761,6 +834,7 @@ int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
 int kid_compact_bergs(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   if (h->n == 0) return KID_OK;
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
@@ -810,6 +884,7 @@ int kid_compact_bergs(kid_handle *h) {
 int kid_move_berg_between_cells(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   h->steps_since_sort = 0;
   if (h->n == 0) return KID_OK;
   const long long n = h->n;
@@ -885,7 +960,6 @@ static int launch_berg(kid_handle *h) {
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
   if (h->n == 0) return KID_OK;
   const DevGrid g = dev_grid(h);
-  const unsigned nb = (unsigned)((h->n + 255) / 256);
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profile) {
@@ -893,22 +967,39 @@ static int launch_berg(kid_handle *h) {
     KID_HIP(h, hipEventRecord(e0, h->stream));
   }
 { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
-  const Redo redo{h->d_redo_list, h->d_redo_count};
-  KID_HIP(h, hipMemsetAsync(h->d_redo_count, 0, sizeof(int), h->stream));
   // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
   // (a few per cent: cell crossings, coast bounces, polar cells).  Pass 2 is sized for the worst case and its
   // surplus workgroups exit on the device-side count.
+  // Pipelined (a side stream is set): two halves; the general build of a half runs on the side stream while the main
+  // stream is already in the hot build of the other half (or of the next step): the ~85 us single-wave latency of the
+  // general build leaves the critical path.  Events order a half's hot build behind its own previous general build.
+  const int nparts = (h->pipelined && !h->params.mts && !h->params.footloose && h->n >= 4096) ? 2 : 1;
+  const long long half = ((h->n / 2 + 255) / 256) * 256;
+  for (int part = 0; part < nparts; ++part) {
+    const long long k0 = (nparts == 1) ? 0 : (part == 0 ? 0 : half);
+    const long long klen = (nparts == 1) ? h->n : (part == 0 ? half : h->n - half);
+    const unsigned nbp = (unsigned)((klen + 255) / 256);
+    const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen};
+    hipStream_t gs = (nparts == 2) ? h->side_stream : h->stream;
+    if (h->evG_live[part]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[part], 0));
+    if (nparts == 1 && h->evG_live[1]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[1], 0));
+    if (!h->redo_prezeroed) KID_HIP(h, hipMemsetAsync(redo.count, 0, sizeof(int), h->stream));
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nb), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
-    if (h->profile) (void)hipEventRecord(e1, h->stream); /* the timed kernel is the hot build (pass 1) */               \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nb < 512u ? nb : 512u), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    if (h->profile && part == nparts - 1) (void)hipEventRecord(e1, h->stream); /* the timed kernel is the hot build (pass 1) */   \
+    if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nbp < 512u ? nbp : 512u), dim3(256), 0, gs, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    if (nparts == 2) { (void)hipEventRecord(h->evG[part], gs); h->evG_live[part] = true; } else h->evG_live[part] = false;      \
   } while (0)
-  if (rk && old) KID_LAUNCH(true, true);
-  else if (rk && !old) KID_LAUNCH(true, false);
-  else if (!rk && old) KID_LAUNCH(false, true);
-  else KID_LAUNCH(false, false);
+    if (rk && old) KID_LAUNCH(true, true);
+    else if (rk && !old) KID_LAUNCH(true, false);
+    else if (!rk && old) KID_LAUNCH(false, true);
+    else KID_LAUNCH(false, false);
 #undef KID_LAUNCH
+  }
+  if (nparts == 1) h->evG_live[1] = false;
+  h->redo_prezeroed = false;
   KID_HIP(h, hipGetLastError());
   if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }
   return KID_OK;
@@ -986,6 +1077,7 @@ int kid_get_iceberg_counter(kid_handle *h, int32_t *counter) {
 }
 
 static int launch_gather(kid_handle *h) {
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   const DevGrid g = dev_grid(h);
   const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell, h->d_totals);
@@ -1006,7 +1098,8 @@ int kid_create_gridded_icebergs_fields(kid_handle *h) {
 int kid_step_local(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
-  int rc = kid_zero_accumulators(h);
+  int rc = h->acc_prezeroed ? KID_OK : kid_zero_accumulators(h);  // kid_step_prepare has done it for this step
+  h->acc_prezeroed = false;
   if (rc) return rc;
   const kid_params &p = h->params;
   if (p.mts) {  // IB:5409-5512 with mts=T
@@ -1061,6 +1154,7 @@ int kid_run_step(kid_handle *h, int nsteps) {
 int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalars) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   if (acc) KID_HIP(h, hipMemcpyAsync(acc, h->d_acc, (size_t)KID_NACC * h->ncell * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (out) KID_HIP(h, hipMemcpyAsync(out, h->d_out, (size_t)KID_NOUT * h->ncell * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (scalars) KID_HIP(h, hipMemcpyAsync(scalars, h->d_totals, KID_NSCALAR * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1081,19 +1175,21 @@ int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count) {
 }
 int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count) {
   if (!h) return KID_EINVAL;
-  if (!dev_ptr) { h->d_acc = h->d_acc_own; return KID_OK; }
+  if (!dev_ptr) { h->d_acc = h->d_acc_own; h->acc_prezeroed = false; return KID_OK; }
   if (count < (int64_t)((size_t)KID_NACC * h->ncell + KID_NSCALAR)) { h->err = "accumulator buffer too small"; return KID_EINVAL; }
   h->d_acc = (double *)dev_ptr;
+  h->acc_prezeroed = false;
   return KID_OK;
 }
 
 int kid_last_redo_count(kid_handle *h, int64_t *count) {
   if (!h || !count) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
-  int c = 0;
-  KID_HIP(h, hipMemcpyAsync(&c, h->d_redo_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
+  int c[4] = {0, 0, 0, 0};
+  KID_HIP(h, hipMemcpyAsync(c, h->d_redo_count2, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   KID_HIP(h, hipStreamSynchronize(h->stream));
-  *count = c;
+  *count = (int64_t)c[0 + h->redo_parity] + (h->pipelined ? (int64_t)c[2 + h->redo_parity] : 0);
   return KID_OK;
 }
 int kid_profile_enable(kid_handle *h, int on) {

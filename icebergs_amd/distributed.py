@@ -102,20 +102,24 @@ class PipelinedStepper:
         self.local_done = [torch.cuda.Event() for _ in range(2)]
         self.gather_done = [torch.cuda.Event() for _ in range(2)]
         self.gather_reads_forcing = needs_footprint_planes(params)   # ustar reads the ocean velocity records
+        # the general build (cell hops, bounces) of each half of the population also goes to the second stream
+        ib.set_stream(self.compute.cuda_stream)
+        ib.set_side_stream(self.comm.cuda_stream, True)
         self.resort_interval, self._since_sort, self.k = resort_interval, 0, 0
 
     def set_forcing_device(self, ptrs):
-        if self.gather_reads_forcing and self.k >= 1:   # the previous gather may still be reading the old records
-            self.compute.wait_event(self.gather_done[(self.k - 1) & 1])
-        self.ib.set_stream(self.compute.cuda_stream)
-        self.ib.set_forcing_device(ptrs)
+        """forcing of the step about to be taken (device addresses); applied by step() in its fused prepass"""
+        self._forcing = list(ptrs)
 
     def step(self):
         torch, ib, cur = self.torch, self.ib, self.k & 1
         if self.k >= 2:
             self.compute.wait_event(self.gather_done[cur])   # block `cur` was last read by the gather of step k-2
+        if self.gather_reads_forcing and self.k >= 1:        # the previous gather may still be reading the old records
+            self.compute.wait_event(self.gather_done[(self.k - 1) & 1])
         ib.bind_accum_buffer(self.acc[cur].data_ptr(), self.count)
         ib.set_stream(self.compute.cuda_stream)
+        ib.step_prepare(getattr(self, "_forcing", None))     # forcing prepass + zeroing of block `cur`, one launch
         ib.step_local()
         self.local_done[cur].record(self.compute)
         with torch.cuda.stream(self.comm):

@@ -97,6 +97,16 @@ module kid_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function kid_step_prepare(h, fields) bind(C, name='kid_step_prepare')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      type(c_ptr), intent(in) :: fields(*)
+    end function
+    integer(c_int) function kid_set_side_stream(h, side_stream, enable) bind(C, name='kid_set_side_stream')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, side_stream
+      integer(c_int), value :: enable
+    end function
     integer(c_int) function kid_last_redo_count(h, count) bind(C, name='kid_last_redo_count')
       import :: c_int, c_ptr, c_int64_t
       type(c_ptr), value :: h

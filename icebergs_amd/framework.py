@@ -81,9 +81,23 @@ class Icebergs:
         arr = (C.c_void_p * T.ENUMS["KID_NFORCING"])(*[C.c_void_p(int(x)) if x else None for x in dev_ptrs])
         self._check(self.lib.kid_set_forcing_device(self.h, arr), "kid_set_forcing_device")
 
+    def step_prepare(self, dev_ptrs=None):
+        """forcing prepass + accumulator zeroing of the coming step in one launch (dev_ptrs as set_forcing_device)"""
+        if dev_ptrs is None:
+            self._check(self.lib.kid_step_prepare(self.h, None), "kid_step_prepare")
+            return
+        key = tuple(int(x) if x else 0 for x in dev_ptrs)
+        if getattr(self, "_prep_key", None) != key:   # the pointer table is rebuilt only when the addresses change
+            self._prep_key = key
+            self._prep_arr = (C.c_void_p * T.ENUMS["KID_NFORCING"])(*[C.c_void_p(x) if x else None for x in key])
+        self._check(self.lib.kid_step_prepare(self.h, self._prep_arr), "kid_step_prepare")
+
     def set_params(self, params):
         self.params = params
         self._check(self.lib.kid_set_params(self.h, C.byref(params)), "kid_set_params")
+
+    def set_side_stream(self, stream_ptr, enable=True):
+        self._check(self.lib.kid_set_side_stream(self.h, C.c_void_p(stream_ptr), 1 if enable else 0), "kid_set_side_stream")
 
     def set_stream(self, stream_ptr):
         self._check(self.lib.kid_set_stream(self.h, C.c_void_p(stream_ptr)), "kid_set_stream")

@@ -53,6 +53,12 @@ int kid_set_params(kid_handle *h, const kid_params *params);
 /* Launch on an existing hipStream_t (e.g. PyTorch's current stream).  NULL names the device's default (null) stream;
  * a handle that is never given a stream uses a private non-blocking one. */
 int kid_set_stream(kid_handle *h, void *hip_stream);
+/* Pipelined launches: with `enable`, a fused per-berg launch goes through the hot build in two halves on the main stream
+ * while the general build (cell hops, bounces; ~85 us of single-wave latency) of each half runs on `side_stream`, under
+ * the hot build of the other half or of the next step.  Every entry point that reads berg state or accumulators on the
+ * main stream first orders itself behind the side stream; a gather launched on the side stream itself is ordered by
+ * that stream (icebergs_amd/distributed.py PipelinedStepper).  Results do not depend on the setting. */
+int kid_set_side_stream(kid_handle *h, void *side_stream, int enable);
 int kid_sync(kid_handle *h);
 const char *kid_last_error(const kid_handle *h);
 const char *kid_version(void);
@@ -80,6 +86,10 @@ int kid_set_resort_interval(kid_handle *h, int steps);
  * switch it off (on = 0) and save 13 stores per berg per step.  Refused (KID_EINVAL at launch) when the stored
  * environment is an input, i.e. .not.old_interp_flds_order.  Default on. */
 int kid_set_store_environment(kid_handle *h, int on);
+
+/* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
+ * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */
+int kid_step_prepare(kid_handle *h, const double *const device_fields[KID_NFORCING]);
 
 /* ---- the hot path, phase by phase (same order as icebergs_run, IB:5423-5512) ---- */
 int kid_zero_accumulators(kid_handle *h);

@@ -142,8 +142,11 @@ def main():
     if rank == 0:
         total_bergs = args.bergs * world
         value = total_bergs * args.steps / elapsed
+        # the dominant kernel is the hot build of berg_kernel: one launch per step, or two (one per half-population)
+        # when the pipelined schedule is on; every berg goes through exactly one of them per step
         kern_ms = berg_ms / max(launches, 1)
-        achieved = ALGO_BYTES_PER_BERG_STEP * args.bergs / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        bergs_per_launch = args.bergs * args.steps / max(launches, 1)
+        achieved = ALGO_BYTES_PER_BERG_STEP * bergs_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is
         # the committed rocprofv3 --pmc measurement of this same command (profiles/r01_hbm_traffic.json), valid only
         # for the population it was taken at
@@ -151,7 +154,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
                 tj = json.load(f)
-            if tj["bergs_per_launch"] == args.bergs:
+            if tj["bergs_per_launch"] == int(round(bergs_per_launch)):
                 traffic, traffic_src = tj["hbm_traffic_bytes_per_launch"], "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; gfx950 fetch correction x2)"
         except (OSError, KeyError, ValueError):
             pass
@@ -167,7 +170,7 @@ def main():
             "per_gpu_value": value / world, "host_submit_ms_per_step": 1e3 * t_submit / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "berg_kernel<true, true, 14u, true> (RK4, old interp order, evolve|thermo|spread, hot build)",
-                         "kernel_ms_avg": kern_ms, "kernel_launches": launches,
+                         "kernel_ms_avg": kern_ms, "kernel_launches": launches, "bergs_per_launch": bergs_per_launch,
                          "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:

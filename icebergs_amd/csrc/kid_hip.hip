@@ -962,10 +962,6 @@ static int launch_berg(kid_handle *h) {
   const DevGrid g = dev_grid(h);
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profile) {
-    KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1));
-    KID_HIP(h, hipEventRecord(e0, h->stream));
-  }
 { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
   // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
   // (a few per cent: cell crossings, coast bounces, polar cells).  Pass 2 is sized for the worst case and its
@@ -984,10 +980,14 @@ static int launch_berg(kid_handle *h) {
     if (h->evG_live[part]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[part], 0));
     if (nparts == 1 && h->evG_live[1]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[1], 0));
     if (!h->redo_prezeroed) KID_HIP(h, hipMemsetAsync(redo.count, 0, sizeof(int), h->stream));
+    if (h->profile) {  // one (start, stop) pair around every hot-build launch
+      KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1));
+      KID_HIP(h, hipEventRecord(e0, h->stream));
+    }
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
-    if (h->profile && part == nparts - 1) (void)hipEventRecord(e1, h->stream); /* the timed kernel is the hot build (pass 1) */   \
+    if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \
     if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nbp < 512u ? nbp : 512u), dim3(256), 0, gs, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
     if (nparts == 2) { (void)hipEventRecord(h->evG[part], gs); h->evG_live[part] = true; } else h->evG_live[part] = false;      \
@@ -1001,7 +1001,6 @@ static int launch_berg(kid_handle *h) {
   if (nparts == 1) h->evG_live[1] = false;
   h->redo_prezeroed = false;
   KID_HIP(h, hipGetLastError());
-  if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }
   return KID_OK;
 }
 

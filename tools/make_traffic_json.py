@@ -1,0 +1,24 @@
+"""profiles/r01_hbm_traffic.json from the two --pmc passes of exp/run_round.sh (FETCH_SIZE, WRITE_SIZE)."""
+import csv, glob, json, collections, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out, grid = {}, []
+for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == c and "berg_kernel" in r["Kernel_Name"]:
+            fast = ", true>" in r["Kernel_Name"]
+            agg["fast" if fast else "general"].append(float(r["Counter_Value"]))
+            if fast: grid.append(int(r["Grid_Size"]))
+    out[c] = {k: {"launches": len(v), "mean_KB": sum(v) / len(v)} for k, v in agg.items()}
+fetch = out["FETCH_SIZE"]["fast"]["mean_KB"] * 1024
+write = out["WRITE_SIZE"]["fast"]["mean_KB"] * 1024
+bergs_per_launch = int(round(sum(grid) / len(grid) / 1000.0)) * 1000   # grid = rows rounded up to 256
+summary = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline",
+           "kernel": "berg_kernel<true, true, 14u, true>", "bergs_per_launch": bergs_per_launch, "raw": out,
+           "fetch_bytes_raw": fetch, "fetch_bytes_corrected": 2 * fetch, "write_bytes": write,
+           "hbm_traffic_bytes_per_launch": 2 * fetch + write,
+           "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) counts 128-B read requests at 64 B on gfx950 -> doubled; WRITE_SIZE (KB) taken as is",
+           "algorithmic_bytes_per_launch": 256.0 * bergs_per_launch}
+json.dump(summary, open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"), "w"), indent=1)
+print(bergs_per_launch, summary["hbm_traffic_bytes_per_launch"], fetch, write)

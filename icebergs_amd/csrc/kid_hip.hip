@@ -297,6 +297,11 @@ __global__ void __launch_bounds__(256) footloose_kernel(const DevGrid g, const k
   footloose_one(g, *pp, b, cx, q, acc, ncell, acc + (size_t)KID_NACC * ncell);
 }
 
+// the device-side tables are rewritten by stream-ordered one-lane kernels (the new contents travel as kernel arguments):
+// no host synchronisation, unlike a copy from pageable memory
+__global__ void set_berg_table_kernel(const BergPtrs src, BergPtrs *dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src; }
+__global__ void set_params_kernel(const kid_params src, kid_params *dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src; }
+
 #include "kid_mts.inc"
 
 // -------------------------------------------------------------------------------------------------------
@@ -433,6 +438,9 @@ struct kid_handle {
   int *d_redo_list2 = nullptr, *d_redo_count2 = nullptr;
   int *d_redo_cnt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [part][parity]: a step's counters are zeroed by its prepass
   int redo_parity = 0; bool redo_prezeroed = false, acc_prezeroed = false;
+  bool uploaded_nonzero[KID_NB_F64] = {};  // fields that held anything but zeros at the last upload
+  bool tail_valid = false;                 // the dead rows are exactly the tail (true between a re-binning and the next launch)
+  bool env_ever_stored = false;            // some launch since the last upload wrote berg%uo..od
   hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   int *d_fl_cursor = nullptr;
@@ -639,6 +647,7 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   if (!h->params.old_interp_flds_order) h->flags.store_env = 1;  // the stored environment is an input again
   return KID_OK;
 }
+static int refresh_tables(kid_handle *h);
 // order the main stream behind general-build launches that are still in flight on the side stream
 static int join_side(kid_handle *h) {
   for (int q = 0; q < 2; ++q)
@@ -793,6 +802,12 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   }
   h->flags.has_static = any_static ? 1 : 0;
   h->flags.has_fl = (any_fl || h->params.footloose) ? 1 : 0;
+  for (int f = 0; f < KID_NB_F64; ++f) {
+    bool nz = false;
+    if (host->f64[f]) for (size_t k = 0; k < n && !nz; ++k) nz = host->f64[f][k] != 0.;
+    h->uploaded_nonzero[f] = nz;
+  }
+  h->tail_valid = false; h->env_ever_stored = false;
   h->n = host->n;
   h->visited = false; h->have_bonds = false;
   KID_HIP(h, hipStreamSynchronize(h->stream));
@@ -827,6 +842,10 @@ int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
     KID_HIP(h, hipMemcpyAsync(&cnt, h->d_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
     KID_HIP(h, hipStreamSynchronize(h->stream));
     *n_alive = (int64_t)cnt;
+    if (h->tail_valid && (int64_t)cnt < h->n) {  // a re-binning left the dead at the tail: drop them now that the count is known
+      h->n = (int64_t)cnt;
+      if (n_slots) *n_slots = h->n;
+    }
   }
   return KID_OK;
 }
@@ -876,6 +895,29 @@ int kid_compact_bergs(kid_handle *h) {
   return KID_OK;
 }
 
+// Fields no kernel of the current configuration ever stores to: if such a field was uploaded as zeros it is zeros
+// forever and a re-binning need not move it (config 2: 32 of the 52 fp64 fields).  Conservative: anything that can
+// append bergs (footloose) or the MTS path writes everything.
+static bool field_never_written(const kid_handle *h, int f) {
+  const kid_params &p = h->params;
+  if (p.footloose || p.mts) return false;
+  switch (f) {
+    case KID_B_AXN_FAST: case KID_B_AYN_FAST: case KID_B_BXN_FAST: case KID_B_BYN_FAST: case KID_B_ANG_VEL: case KID_B_ANG_ACCEL: case KID_B_ROT:
+    case KID_B_UVEL_OLD: case KID_B_VVEL_OLD: case KID_B_LON_OLD: case KID_B_LAT_OLD:
+    case KID_B_HALO_BERG: case KID_B_STATIC_BERG: case KID_B_START_LON: case KID_B_START_LAT: case KID_B_START_MASS: case KID_B_HEAT_DENSITY:
+      return true;
+    case KID_B_UVEL_PREV: case KID_B_VVEL_PREV:
+      return p.Runge_not_Verlet != 0;
+    case KID_B_MASS_OF_FL_BITS: case KID_B_MASS_OF_FL_BERGY_BITS: case KID_B_FL_K: case KID_B_START_DAY: case KID_B_MASS_SCALING:
+      return h->flags.has_fl == 0;
+    case KID_B_UO: case KID_B_VO: case KID_B_UI: case KID_B_VI: case KID_B_UA: case KID_B_VA: case KID_B_SSH_X: case KID_B_SSH_Y:
+    case KID_B_SST: case KID_B_SSS: case KID_B_CN: case KID_B_HI: case KID_B_OD:
+      return !h->env_ever_stored;
+    default:
+      return false;
+  }
+}
+
 // move_berg_between_cells (IB:5437, FW:1758-1797): re-bin the bergs after they moved.  With per-cell linked lists
 // that is list surgery; on the SoA it is a stable device radix sort by cell index (j-major, i-minor: the reference's
 // traversal order, IB:7106) followed by a gather of every field.  Dead bergs sort to the end and are dropped.
@@ -906,11 +948,9 @@ int kid_move_berg_between_cells(kid_handle *h) {
                      h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_idx[0], n);
   size_t tmp = h->sort_tmp_bytes;
   KID_HIP(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)n, 0u, bits, h->stream));
-  int64_t n_alive = 0;
-  int rc = kid_num_bergs(h, nullptr, &n_alive);
-  if (rc) return rc;
   const unsigned *perm = h->d_idx[1];
   for (int f = 0; f < KID_NB_F64; ++f) {
+    if (!h->uploaded_nonzero[f] && field_never_written(h, f)) continue;  // all zeros, before and after
     hipLaunchKernelGGL(permute_kernel<double>, dim3(nb), dim3(256), 0, h->stream, h->bp.f[f], h->d_perm_spare, perm, n);
     std::swap(h->bp.f[f], h->d_perm_spare);
   }
@@ -925,9 +965,10 @@ int kid_move_berg_between_cells(kid_handle *h) {
     unsigned *old = (unsigned *)h->bp.i[f]; h->bp.i[f] = spare; h->d_key[0] = old;
   }
   KID_HIP(h, hipGetLastError());
-  h->n = n_alive;  // the dead sorted to the tail
+  // the dead sorted to the tail; they are dropped the next time the host asks for the count (no synchronisation here)
+  h->tail_valid = true;
   h->tables_dirty = true;
-  return KID_OK;
+  return refresh_tables(h);
 }
 int kid_set_resort_interval(kid_handle *h, int steps) {
   if (!h || steps < 0) return KID_EINVAL;
@@ -963,6 +1004,8 @@ static int launch_berg(kid_handle *h) {
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
+  h->tail_valid = false;
+  if (h->flags.store_env || !old) h->env_ever_stored = true;
   // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
   // (a few per cent: cell crossings, coast bounces, polar cells).  Pass 2 is sized for the worst case and its
   // surplus workgroups exit on the device-side count.
@@ -1030,10 +1073,12 @@ int kid_thermodynamics(kid_handle *h) {
   return launch_berg<PH_THERMO>(h);
 }
 static int refresh_tables(kid_handle *h) {
-  if (h->tables_dirty) {  // refresh the device-side tables (pageable host source: effectively synchronous)
-    KID_HIP(h, hipMemcpyAsync(h->d_bp, &h->bp, sizeof(BergPtrs), hipMemcpyHostToDevice, h->stream));
-    KID_HIP(h, hipMemcpyAsync(h->d_params, &h->params, sizeof(kid_params), hipMemcpyHostToDevice, h->stream));
-    KID_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->tables_dirty) {
+    const int rc = join_side(h);  // a general-build launch on the side stream may still be reading the tables
+    if (rc) return rc;
+    hipLaunchKernelGGL(set_berg_table_kernel, dim3(1), dim3(64), 0, h->stream, h->bp, h->d_bp);
+    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(64), 0, h->stream, h->params, h->d_params);
+    KID_HIP(h, hipGetLastError());
     h->tables_dirty = false;
   }
   return KID_OK;

@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bergs", type=int, default=1_000_000, help="bergs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="keep the general build, the all-reduce and the gather on the critical path")
+    ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce and the gather on the critical path")
+    ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)
@@ -95,24 +96,20 @@ def main():
     from icebergs_amd.distributed import ShardedStepper, PipelinedStepper, accumulator_views
     _, count = ib.accum_device_ptr()
     multi = world > 1 or args.force_collective
-    if not args.no_pipeline:
-        # the general build of each half-population, the all-reduce (N>1) and the gather of step k run on a second
-        # stream under the hot-build kernels of the other half / of step k+1
-        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective)
+    pipelined = (multi and not args.no_pipeline) or args.split_general
+    if pipelined:
+        # N>1: the all-reduce and the gather of step k run on a second stream under the per-berg kernels of step k+1
+        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective, split_general=args.split_general)
         nreduced = stepper.views[0][0].numel()
-
-        def step():
-            stepper.set_forcing_device(forcing_ptrs)
-            stepper.step()
     else:
         acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
         ib.bind_accum_buffer(acc_t.data_ptr(), count)
         stepper = ShardedStepper(ib, acc_t, ib.ncell, params.diag_mask, dist, params=params, force_collective=args.force_collective)
         nreduced = stepper.planes.numel()
 
-        def step():
-            ib.set_forcing_device(forcing_ptrs)      # forcing prepass: per-cell records built on the device
-            stepper.step()                           # fused per-berg kernels; RCCL all-reduce (N>1); 9-point gather
+    def step():
+        stepper.set_forcing_device(forcing_ptrs)     # applied by the step's prepass: per-cell forcing records + accumulator zeroing
+        stepper.step()                               # per-berg kernels; RCCL all-reduce (N>1); 9-point gather
 
     def fence():
         stepper.flush()
@@ -165,7 +162,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
                                    "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s, ignore_traj=T" % args.bergs,
                        "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
-                       "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, "" if args.no_pipeline else ", overlapped with the next step's kernels")) if multi else "none (1 GPU)",
+                       "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, ", overlapped with the next step's kernels" if pipelined else "")) if multi else "none (1 GPU)",
                        "bergs_alive_at_end": n_alive},
             "per_gpu_value": value / world, "host_submit_ms_per_step": 1e3 * t_submit / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

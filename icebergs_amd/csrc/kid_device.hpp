@@ -41,6 +41,11 @@ struct DevGrid {
   const TrcRec *trc;
   const GeoRec *geo;
   const double *dx, *dy, *ocean_depth, *ssh;
+  // Parameter-only subexpressions of the hot loop, evaluated once on the host with the same IEEE operations (so the
+  // results are the ones every lane used to compute for itself, per RK4 stage): sin(pi/180*lat_ref) alone was 7 % of
+  // the step
+  double sin_lat_ref;  // f-plane / Cartesian Coriolis, IB:2043-2047
+  double pi_180, r180_pi, dydl, rho_ratio;  // pi/180, 180/pi, (180/pi)/Rearth (IB:462-477), rho_bergs/rho_seawater (IB:2052)
   __device__ __forceinline__ int idx(int i, int j) const { return (i - isd) + (j - jsd) * ni; }
 };
 
@@ -367,7 +372,7 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   const double uo = e.uo, vo = e.vo, ui = e.ui, vi = e.vi, ua = e.ua, va = e.va;
   const double f_cori = (2. * p.omega) * sin_lat;  // IB:2043-2047, the caller picks lat or lat_ref
   const double M = bg.M, T = bg.T, W = bg.W, L = bg.L;
-  const double D = (p.rho_bergs / RHO_SEAWATER) * T, F = T - D;
+  const double D = g.rho_ratio * T, F = T - D;
   const double hi = dmin(e.hi, D), D_hi = dmax(0., D - hi);
   double c_gnd = 0.;
   {  // grounding drag IB:2068-2082
@@ -403,10 +408,13 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   double uveln = new_pc ? uvel0 : uvel, vveln = new_pc ? vvel0 : vvel;
   // the |V0 - V_x| halves of the predictive-corrective drag do not change between the two passes
   double s0o = 0., s0a = 0., s0i = 0.;
+  // no lane of the wave has sea ice (c_ice = 0 everywhere, e.g. config 2): drag_ice = 0 * (...) is 0 whatever the
+  // speeds are, so its three square roots per pass are skipped -- bitwise the same result
+  const bool any_ice = __ballot(c_ice != 0.) != 0ull;
   if (new_pc) {
     s0o = sqrt((uvel0 - uo) * (uvel0 - uo) + (vvel0 - vo) * (vvel0 - vo));
     s0a = sqrt((uvel0 - ua) * (uvel0 - ua) + (vvel0 - va) * (vvel0 - va));
-    s0i = sqrt((uvel0 - ui) * (uvel0 - ui) + (vvel0 - vi) * (vvel0 - vi));
+    if (any_ice) s0i = sqrt((uvel0 - ui) * (uvel0 - ui) + (vvel0 - vi) * (vvel0 - vi));
   }
   const double A12_0 = RK ? -0. * dt * f_cori : (-1. * dt * f_cori) / 2.;  // IB:2244-2251 (alpha, C_N)
   const double A21_0 = RK ? 0. * dt * f_cori : (1. * dt * f_cori) / 2.;
@@ -417,12 +425,12 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
     if (new_pc) {
       drag_ocn = c_ocn * 0.5 * (sqrt((uveln - uo) * (uveln - uo) + (vveln - vo) * (vveln - vo)) + s0o);
       drag_atm = c_atm * 0.5 * (sqrt((uveln - ua) * (uveln - ua) + (vveln - va) * (vveln - va)) + s0a);
-      drag_ice = c_ice * 0.5 * (sqrt((uveln - ui) * (uveln - ui) + (vveln - vi) * (vveln - vi)) + s0i);
+      drag_ice = any_ice ? c_ice * 0.5 * (sqrt((uveln - ui) * (uveln - ui) + (vveln - vi) * (vveln - vi)) + s0i) : 0.;
     } else {
       const double us = 0.5 * (uveln + uvel), vs = 0.5 * (vveln + vvel);
       drag_ocn = c_ocn * sqrt((us - uo) * (us - uo) + (vs - vo) * (vs - vo));
       drag_atm = c_atm * sqrt((us - ua) * (us - ua) + (vs - va) * (vs - va));
-      drag_ice = c_ice * sqrt((us - ui) * (us - ui) + (vs - vi) * (vs - vi));
+      drag_ice = any_ice ? c_ice * sqrt((us - ui) * (us - ui) + (vs - vi) * (vs - vi)) : 0.;
     }
     const double drag_gnd = c_gnd;
     double RHS_x = (axn_l / 2) + bxn_l, RHS_y = (ayn_l / 2) + byn_l;
@@ -528,16 +536,43 @@ __device__ __noinline__ void rotvec_from_tang(const kid_params &p, double lon, d
 }
 
 // sin(lat) for Coriolis (IB:2043-2047) and the metric dlon/dx (IB:462-477) share one argument reduction
-struct LatTerms { double sin_f, dxdl; };
+struct LatTerms { double sin_f, dxdl, s, c; };
 __device__ __forceinline__ LatTerms lat_terms(const DevGrid &g, const kid_params &p, double lat, double sin_ref) {
   LatTerms t;
   if (g.latlon) {
     double s, c;
-    sincos(lat * (p.pi / 180.), &s, &c);
-    t.dxdl = (180. / p.pi) / (p.Rearth * c);
+    sincos(lat * g.pi_180, &s, &c);
+    t.dxdl = g.r180_pi / (p.Rearth * c);
     t.sin_f = p.use_f_plane ? sin_ref : s;
-  } else { t.dxdl = 1.; t.sin_f = sin_ref; }
+    t.s = s; t.c = c;
+  } else { t.dxdl = 1.; t.sin_f = sin_ref; t.s = 0.; t.c = 1.; }
   return t;
+}
+
+// RK4 stages 2-4 sit within a few hundred metres of stage 1: sin/cos of lat1 + d come from the angle-addition formulas
+// with a 5th/4th-order Taylor series in d (|d| < 2e-3 rad: truncation < 1e-17), ~20 instructions instead of a sincos
+// with argument reduction (~150).  Not bitwise equal to sincos(lat) (differences ~1e-16); -DKID_EXACT_MATH keeps sincos.
+__device__ __forceinline__ LatTerms lat_terms_near(const DevGrid &g, const kid_params &p, double lat, double sin_ref,
+                                                   double lat1, double s1, double c1) {
+#ifdef KID_EXACT_MATH
+  (void)lat1; (void)s1; (void)c1;
+  return lat_terms(g, p, lat, sin_ref);
+#else
+  LatTerms t;
+  if (!g.latlon) { t.dxdl = 1.; t.sin_f = sin_ref; t.s = 0.; t.c = 1.; return t; }
+  const double d = (lat - lat1) * g.pi_180;
+  double s, c;
+  if (fabs(d) < 2.e-3) {
+    const double d2 = d * d;
+    const double sd = d * (1. - d2 * (1. / 6.) * (1. - d2 * (1. / 20.)));
+    const double cd = 1. - d2 * 0.5 * (1. - d2 * (1. / 12.));
+    s = s1 * cd + c1 * sd; c = c1 * cd - s1 * sd;
+  } else sincos(lat * g.pi_180, &s, &c);
+  t.dxdl = g.r180_pi / (p.Rearth * c);
+  t.sin_f = p.use_f_plane ? sin_ref : s;
+  t.s = s; t.c = c;
+  return t;
+#endif
 }
 
 // per-berg dynamic state carried through one step
@@ -559,8 +594,8 @@ template <bool OLD_ORDER, bool FAST>
 __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
                                          BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
   const double dt = p.dt, dt_2 = 0.5 * dt, dt_6 = dt / 6.;
-  const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
-  const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
+  const double sin_ref = g.sin_lat_ref;
+  const double dydl = g.latlon ? g.dydl : 1.;
   const int i1 = d.ine, j1 = d.jne;
   const double xi1 = d.xi, yj1 = d.yj, lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
   const bool on_tang = FAST ? false : ((lat1 > 89.) && g.latlon);
@@ -573,13 +608,16 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   double Au = 0., Bu = 0., Av = 0., Bv = 0., Aax = 0., Bax = 0., Aay = 0., Bay = 0., Aaxn = 0., Baxn = 0., Aayn = 0., Bayn = 0.;
   double lon_s = lon1, lat_s = lat1, uvel_s = uvel1, vvel_s = vvel1, xdot_s = xdot1, ydot_s = ydot1;
   int i = i1, j = j1; double xi = xi1, yj = yj1;
+  double s_lat1 = 0., c_lat1 = 1.;
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     KID_MARK("loop_top");
     if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
     KID_PHASE_FENCE();
     KID_MARK("after_adjust");
-    const LatTerms lt = lat_terms(g, p, lat_s, sin_ref);
+    LatTerms lt;
+    if (s == 0) { lt = lat_terms(g, p, lat_s, sin_ref); s_lat1 = lt.s; c_lat1 = lt.c; }
+    else lt = lat_terms_near(g, p, lat_s, sin_ref, lat1, s_lat1, c_lat1);
     double qu = uvel_s * lt.dxdl, qv = vvel_s * dydl;          // u_k, v_k  IB:7412
     KID_PHASE_FENCE();
     double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
@@ -648,8 +686,8 @@ template <bool OLD_ORDER, bool FAST>
 __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
                                             BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
   const double dt = p.dt, dt_2 = 0.5 * dt;
-  const double sin_ref = sin((p.pi / 180.) * p.lat_ref);
-  const double dydl = g.latlon ? (180. / p.pi) / p.Rearth : 1.;
+  const double sin_ref = g.sin_lat_ref;
+  const double dydl = g.latlon ? g.dydl : 1.;
   const double lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
   double axn = d.axn, ayn = d.ayn, bxn = d.bxn, byn = d.byn;
   d.uvel_prev = d.uvel - dt_2 * d.bxn; d.vvel_prev = d.vvel - dt_2 * d.byn;       // IB:7256

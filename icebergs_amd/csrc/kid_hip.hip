@@ -125,8 +125,9 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   __shared__ double lds_pk[FAST ? 4 * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the 4 waves (hot build)
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
   const long long total = FAST ? redo.klen : (long long)(*redo.count);
-  for (long long tid = (long long)blockIdx.x * 256ll + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * 256ll + threadIdx.x) : (tid - threadIdx.x < total));
-       tid += (long long)gridDim.x * 256ll) {
+  const long long bdim = FAST ? 256ll : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
+  for (long long tid = (long long)blockIdx.x * bdim + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * bdim + threadIdx.x) : (tid - threadIdx.x < total));
+       tid += (long long)gridDim.x * bdim) {
   const bool inrange = tid < total;
   const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
@@ -482,6 +483,9 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.vel = h->d_vel; g.trc = h->d_trc; g.geo = h->d_geo;
   g.dx = h->d_static[KID_G_DX]; g.dy = h->d_static[KID_G_DY]; g.ocean_depth = h->d_static[KID_G_OCEAN_DEPTH];
   g.ssh = h->d_forcing[KID_F_SSH];
+  g.sin_lat_ref = sin((h->params.pi / 180.) * h->params.lat_ref);
+  g.pi_180 = h->params.pi / 180.; g.r180_pi = 180. / h->params.pi; g.dydl = (180. / h->params.pi) / h->params.Rearth;
+  g.rho_ratio = h->params.rho_bergs / RHO_SEAWATER;
   return g;
 }
 // area/Uvel/Vvel_on_ocean (27 planes) are intermediates of spread_area / spread_uvel / spread_vvel / ustar_iceberg
@@ -1032,7 +1036,7 @@ static int launch_berg(kid_handle *h) {
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \
     if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nbp < 512u ? nbp : 512u), dim3(256), 0, gs, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(4u * nbp < 2048u ? 4u * nbp : 2048u), dim3(64), 0, gs, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
     if (nparts == 2) { (void)hipEventRecord(h->evG[part], gs); h->evG_live[part] = true; } else h->evG_live[part] = false;      \
   } while (0)
     if (rk && old) KID_LAUNCH(true, true);

@@ -64,7 +64,13 @@ class ShardedStepper:
         self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
         self.planes, self.scalars = accumulator_views(acc_block, ncell, diag_mask, params)
 
+    def set_forcing_device(self, ptrs):
+        """forcing of the step about to be taken (device addresses); applied by step() in its fused prepass"""
+        self._forcing = list(ptrs)
+
     def step(self):
+        if hasattr(self.backend, "step_prepare"):
+            self.backend.step_prepare(getattr(self, "_forcing", None))   # forcing prepass + accumulator zeroing, one launch
         self.backend.step_local()
         if self.dist is not None:
             self.dist.all_reduce(self.planes)
@@ -89,7 +95,7 @@ class PipelinedStepper:
     while the compute stream is already zeroing and filling the other block.  `flush()` joins both streams; outputs
     (kid_get_accumulators) are those of the last flushed step."""
 
-    def __init__(self, ib, params, dist=None, resort_interval=16, force_collective=False):
+    def __init__(self, ib, params, dist=None, resort_interval=16, force_collective=False, split_general=False):
         import torch
         self.torch, self.ib, self.params = torch, ib, params
         self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
@@ -102,9 +108,11 @@ class PipelinedStepper:
         self.local_done = [torch.cuda.Event() for _ in range(2)]
         self.gather_done = [torch.cuda.Event() for _ in range(2)]
         self.gather_reads_forcing = needs_footprint_planes(params)   # ustar reads the ocean velocity records
-        # the general build (cell hops, bounces) of each half of the population also goes to the second stream
+        # split_general: the general build (cell hops, bounces) of each half of the population also goes to the second
+        # stream (kid_set_side_stream).  Measured on one MI355X it does not pay at 1e6 bergs: two half launches of the hot
+        # build cost ~30 us more than one and the four cross-stream dependencies ~45 us, against ~65 us hidden.
         ib.set_stream(self.compute.cuda_stream)
-        ib.set_side_stream(self.comm.cuda_stream, True)
+        ib.set_side_stream(self.comm.cuda_stream, bool(split_general))
         self.resort_interval, self._since_sort, self.k = resort_interval, 0, 0
 
     def set_forcing_device(self, ptrs):

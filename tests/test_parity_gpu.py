@@ -273,7 +273,8 @@ def test_c4_mts_dem(oracle, case):
         assert (refbd["broken"] != 0).sum() > 0  # the case does fracture
 
 
-def test_pipelined_stepper_matches_plain(oracle):
+@pytest.mark.parametrize("split_general", [False, True])
+def test_pipelined_stepper_matches_plain(oracle, split_general):
     """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)
     must give what the plain sequence gives; run here on one GPU, with and without a (world-size-1) RCCL all-reduce."""
     import torch
@@ -297,10 +298,10 @@ def test_pipelined_stepper_matches_plain(oracle):
                 ib.bind_accum_buffer(acc_t.data_ptr(), count)
                 st = ShardedStepper(ib, acc_t, ib.ncell, p.diag_mask, None, params=p)
                 for _ in range(nsteps):
-                    ib.set_forcing_device(ptrs)
+                    st.set_forcing_device(ptrs)
                     st.step()
             else:
-                st = PipelinedStepper(ib, p, None)
+                st = PipelinedStepper(ib, p, None, split_general=split_general)
                 for _ in range(nsteps):
                     st.set_forcing_device(ptrs)
                     st.step()

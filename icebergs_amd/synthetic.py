@@ -344,7 +344,7 @@ def bond_neighbours(b, n, reach, max_bonds=6):
 
 def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45, nj=45, gridres=5000.0, sub_steps=200,
               bump=(58.0e3, 60.0e3), bump_depth=50.0, origin=(44137.0, 35211.0), frac=(1850.0, 1000.0), thickness_jitter=0.0,
-              seed=4, two_bergs=False):
+              seed=4, two_bergs=False, dem=True, explicit_inner=True, spring_coef=None, dt=1800.0):
     """BASELINE config 4 family: a tabular berg made of bonded DEM elements (hexagonal or square packing) drifting at
     0.1 m/s onto a Gaussian seamount on the Cartesian grid of tests/dem_ground_frac_test (driver DRV:288-307,
     namelist tests/dem_ground_frac_test/input.nml): MTS velocity Verlet with explicit DEM sub-steps, stress fracture
@@ -427,6 +427,15 @@ def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45
     b["start_year"][:] = 1
     b["start_day"][:] = 1.0e-6 * np.arange(n)
     p.constant_length = p.constant_width = float(w)
+    if not dem:   # Stern et al. (2017) KID springs between bonded elements instead of the DEM bonds (tests/collision_tests/input_MTS_KID.nml)
+        p.dem, p.explicit_inner_mts = 0, 1 if explicit_inner else 0
+        p.use_broken_bonds_for_substep_contact = p.break_bonds_on_sub_steps = p.short_step_mts_grounding = 0
+        p.fracture_criterion_stress, p.frac_thres_n, p.frac_thres_t = 0, 0.0, 0.0
+        p.radial_damping_coef, p.tangental_damping_coef = 1.0e-4, 2.0e-5
+        p.convergence_tolerance = 1.0e-8
+    if spring_coef is not None:
+        p.spring_coef = spring_coef
+    p.dt = dt
     b = sort_reference_order(b)
     bd = bond_neighbours(b, n, 2.0 * radius * 1.05, p.max_bonds)
     return grid, p, b, bd

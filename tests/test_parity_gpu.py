@@ -253,7 +253,8 @@ def test_store_environment_off(oracle):
         ib.close()
 
 
-@pytest.mark.parametrize("case", ["hex_free", "hex_grounded", "square_free", "two_bergs", "thickness_jitter"])
+@pytest.mark.parametrize("case", ["hex_free", "hex_grounded", "square_free", "two_bergs", "thickness_jitter",
+                                  "kid_explicit", "kid_implicit", "kid_two_bergs"])
 def test_c4_mts_dem(oracle, case):
     """BASELINE config 4 family at oracle size: bonded DEM elements under MTS velocity Verlet (200 explicit sub-steps
     per step), grounding on a seamount with stress fracture, square and hexagonal packing, a collision between two
@@ -261,7 +262,13 @@ def test_c4_mts_dem(oracle, case):
     kw = {"hex_free": dict(bump=(150e3, 150e3)), "hex_grounded": dict(),
           "square_free": dict(bump=(150e3, 150e3), hexagonal=False, nx=6, ny=6),
           "two_bergs": dict(bump=(150e3, 150e3), two_bergs=True, hexagonal=False, nx=4, ny=6),
-          "thickness_jitter": dict(bump=(150e3, 150e3), thickness_jitter=0.2)}[case]
+          "thickness_jitter": dict(bump=(150e3, 150e3), thickness_jitter=0.2),
+          # MTS without DEM (tests/collision_tests/input_MTS_KID.nml): KID springs on the bonds, explicit inner steps, or
+          # the implicit inner iteration with force_convergence; then two conglomerates colliding
+          "kid_explicit": dict(bump=(150e3, 150e3), dem=False, explicit_inner=True, spring_coef=1e-5, sub_steps=120, dt=3600.0),
+          "kid_implicit": dict(bump=(150e3, 150e3), dem=False, explicit_inner=False, spring_coef=1e-5, sub_steps=20, dt=1800.0),
+          "kid_two_bergs": dict(bump=(150e3, 150e3), dem=False, explicit_inner=True, spring_coef=1e-5, sub_steps=60, dt=3600.0,
+                                two_bergs=True, hexagonal=False, nx=4, ny=6)}[case]
     grid, p, b, bd = S.config_c4(**kw)
     S.set_diag_all(p)
     nsteps = 6

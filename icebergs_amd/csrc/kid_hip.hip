@@ -515,7 +515,10 @@ static int check_params(kid_handle *h, const kid_params *p) {
       h->err = "use_broken_bonds_for_substep_contact requires break_bonds_on_sub_steps, dem and iceberg_bonds_on (FW:1438-1447)"; return KID_EINVAL; }
     if (p->footloose) { h->err = "footloose together with mts is not implemented"; return KID_EUNSUPPORTED; }
   } else if (p->interactive_icebergs_on || p->iceberg_bonds_on) {
-    h->err = "interacting / bonded bergs are implemented for the MTS scheme only (mts=T)"; return KID_EUNSUPPORTED;
+    if (p->Runge_not_Verlet) { h->err = "interacting / bonded bergs under the single-time-step scheme are implemented for Verlet only (Runge_not_Verlet=F)"; return KID_EUNSUPPORTED; }
+    if (p->footloose) { h->err = "footloose together with interacting bergs is not implemented"; return KID_EUNSUPPORTED; }
+    if (p->iceberg_bonds_on && !p->interactive_icebergs_on) { h->err = "iceberg_bonds_on without interactive_icebergs_on is not implemented"; return KID_EUNSUPPORTED; }
+    if (p->max_bonds < 1 || p->max_bonds > KID_MAX_BONDS) { h->err = "max_bonds out of range"; return KID_EINVAL; }
   }
   if (p->tidal_drift > 0.) { h->err = "tidal_drift needs FMS's random stream: not supported"; return KID_EUNSUPPORTED; }
   if (p->time_average_weight) { h->err = "time_average_weight is not implemented"; return KID_EUNSUPPORTED; }
@@ -933,6 +936,7 @@ int kid_move_berg_between_cells(kid_handle *h) {
   { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   h->steps_since_sort = 0;
   if (h->n == 0) return KID_OK;
+  if (h->have_bonds) { h->err = "bergs with bonds keep their rows: no re-binning while bond tables exist"; return KID_EUNSUPPORTED; }
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (!h->d_key[0]) {
@@ -1055,6 +1059,7 @@ extern "C" {
 
 static int mts_depth(kid_handle *h);
 int kid_evolve_icebergs_mts(kid_handle *h);
+int kid_evolve_icebergs_interactive(kid_handle *h);
 int kid_interp_gridded_fields_to_bergs(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
@@ -1067,6 +1072,7 @@ int kid_evolve_icebergs(kid_handle *h) {
   KID_HIP(h, hipSetDevice(h->device));
   if (h->params.static_icebergs) return KID_OK;  // IB:5428
   if (h->params.mts) return kid_evolve_icebergs_mts(h);  // IB:5431
+  if (h->params.interactive_icebergs_on) return kid_evolve_icebergs_interactive(h);
   return launch_berg<PH_EVOLVE>(h);
 }
 int kid_thermodynamics(kid_handle *h) {
@@ -1159,6 +1165,14 @@ int kid_step_local(kid_handle *h) {
     if (rc) return rc;
     return launch_berg<PH_THERMO | PH_SPREAD>(h);
   }
+  if (p.interactive_icebergs_on) {  // single-time-step scheme with interactions, IB:5409-5512
+    const bool contact = (p.contact_distance > 0.) || (p.contact_spring_coef != p.spring_coef);
+    if (!h->visited) { rc = sts_ia_first_visit(h); if (rc) return rc; }
+    if (!p.old_interp_flds_order) { rc = launch_berg<PH_INTERP>(h); if (rc) return rc; }
+    if (!p.static_icebergs) { rc = kid_evolve_icebergs_interactive(h); if (rc) return rc; }
+    if (contact) { rc = kid_set_conglom_ids(h); if (rc) return rc; }   // IB:5470-5471
+    return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
+  }
   if (p.footloose) {  // calving sits between evolve and thermodynamics (IB:5453) and appends bergs: three launches
     rc = launch_berg<PH_INTERP | PH_EVOLVE>(h);
     if (rc) return rc;
@@ -1191,7 +1205,7 @@ int kid_run_step(kid_handle *h, int nsteps) {
     if (rc) return rc;
     rc = kid_step_gather(h);
     if (rc) return rc;
-    if (!h->params.mts && h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised; bonded bergs keep their rows
+    if (!h->params.mts && !h->params.interactive_icebergs_on && h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised; bonded bergs keep their rows
       rc = kid_move_berg_between_cells(h);
       if (rc) return rc;
     }

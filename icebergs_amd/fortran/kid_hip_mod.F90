@@ -126,6 +126,10 @@ module kid_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: h
     end function
+    integer(c_int) function kid_evolve_icebergs_interactive(h) bind(C, name='kid_evolve_icebergs_interactive')  ! IB:5433 with interactive bergs
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
     integer(c_int) function kid_set_conglom_ids(h) bind(C, name='kid_set_conglom_ids')           ! IB:5459 / FW:2601
       import :: c_int, c_ptr
       type(c_ptr), value :: h

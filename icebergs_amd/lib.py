@@ -19,7 +19,7 @@ SYMBOLS = [
     "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
     "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
     "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
-    "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids",
+    "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
 ]
 
 
@@ -67,6 +67,7 @@ def load():
     lib.kid_download_bonds.argtypes = [H, C.POINTER(T.BondSoA)]
     lib.kid_evolve_icebergs_mts.argtypes = [H]
     lib.kid_set_conglom_ids.argtypes = [H]
+    lib.kid_evolve_icebergs_interactive.argtypes = [H]
     lib.kid_download_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_num_bergs.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.kid_set_resort_interval.argtypes = [H, C.c_int]

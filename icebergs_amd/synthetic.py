@@ -344,7 +344,7 @@ def bond_neighbours(b, n, reach, max_bonds=6):
 
 def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45, nj=45, gridres=5000.0, sub_steps=200,
               bump=(58.0e3, 60.0e3), bump_depth=50.0, origin=(44137.0, 35211.0), frac=(1850.0, 1000.0), thickness_jitter=0.0,
-              seed=4, two_bergs=False, dem=True, explicit_inner=True, spring_coef=None, dt=1800.0):
+              seed=4, two_bergs=False, dem=True, explicit_inner=True, spring_coef=None, dt=1800.0, mts=True, contact=True):
     """BASELINE config 4 family: a tabular berg made of bonded DEM elements (hexagonal or square packing) drifting at
     0.1 m/s onto a Gaussian seamount on the Cartesian grid of tests/dem_ground_frac_test (driver DRV:288-307,
     namelist tests/dem_ground_frac_test/input.nml): MTS velocity Verlet with explicit DEM sub-steps, stress fracture
@@ -435,6 +435,11 @@ def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45
         p.convergence_tolerance = 1.0e-8
     if spring_coef is not None:
         p.spring_coef = spring_coef
+    if not mts:   # single-time-step KID (tests/collision_tests/input_KID.nml): Verlet, springs + implicit damping inside accel
+        p.mts, p.dem, p.explicit_inner_mts, p.force_convergence, p.mts_sub_steps = 0, 0, 0, 0, 1
+        p.old_interp_flds_order = 1
+    if not contact:   # Stern et al.'s original interaction: 3x3 cells, every berg, no separate contact spring
+        p.contact_distance, p.contact_spring_coef = 0.0, p.spring_coef
     p.dt = dt
     b = sort_reference_order(b)
     bd = bond_neighbours(b, n, 2.0 * radius * 1.05, p.max_bonds)

@@ -111,6 +111,10 @@ int kid_upload_bonds(kid_handle *h, const kid_bond_soa *host);
 int kid_download_bonds(kid_handle *h, kid_bond_soa *host);
 int kid_evolve_icebergs_mts(kid_handle *h);
 int kid_set_conglom_ids(kid_handle *h);
+/* evolve_icebergs (IB:7081-7200) with interactive_icebergs_on under the single-time-step Verlet scheme: velocity sweep
+ * with the spring/damping terms of interactive_force inside accel, then the position sweep (kid_evolve_icebergs
+ * dispatches to it when interactive_icebergs_on and mts=F) */
+int kid_evolve_icebergs_interactive(kid_handle *h);
 
 /* grd%iceberg_counter_grd (FW:1017), the per-cell counter generate_id draws berg ids from; (isd:ied,jsd:jed) int32 */
 int kid_set_iceberg_counter(kid_handle *h, const int32_t *counter);

@@ -82,6 +82,9 @@ double ko_quad_interp_depth(const ko_grid *g, const kid_params *p, double x, dou
 void ko_run_step_mts(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
                      double *acc, double *out, double *scalars);
 
+void ko_evolve_icebergs_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars);
+void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
+                             double *acc, double *out, double *scalars);
 void ko_default_params(kid_params *p);
 int64_t ko_sizeof(int which);
 

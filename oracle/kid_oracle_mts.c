@@ -920,6 +920,199 @@ void ko_evolve_icebergs_mts(const ko_grid *g, const kid_params *p, kid_berg_soa 
   ctx_free(c);
 }
 
+/* ---- the single-time-step scheme with interacting bergs (interactive_icebergs_on, mts=.false.) ------------------
+ * accel IB:1950-2442 with the interactive terms; evolve_icebergs IB:7081-7200 (first sweep: velocities, second sweep:
+ * update_verlet_position + the *_old copies the next step's interactive_force reads).  Verlet only. */
+static void accel_sts_ia(mts_ctx *c, int64_t k, int i, int j, double xi, double yj, double lat, double uvel, double vvel,
+                         double uvel0, double vvel0, double dt, double *ax, double *ay, double *axn, double *ayn, double *bxn, double *byn) {
+  const kid_params *p = c->p; const ko_grid *g = c->g;
+  const double pi_180 = p->pi / 180.;
+  const double Cr0 = 0.06;
+  const int RK = p->Runge_not_Verlet;
+  const double alpha = RK ? 0.0 : 1.0, beta = 1.0, C_N = RK ? 0.0 : 1.0;
+  const int new_pc = RK ? p->use_new_predictive_corrective : 1;
+  const double u_star = uvel0 + (*axn * (dt / 2.)), v_star = vvel0 + (*ayn * (dt / 2.));
+  double env[13];
+  if (p->old_interp_flds_order) ko_interp_flds(g, p, BF(KID_B_LON, k), BF(KID_B_LAT, k), i, j, xi, yj, env);
+  else for (int e = 0; e < 13; ++e) env[e] = BF(KID_B_UO + e, k);
+  const double uo = env[0], vo = env[1], ui = env[2], vi = env[3], ua = env[4], va = env[5], ssh_x = env[6], ssh_y = env[7];
+  double hi = env[11]; const double od = env[12];
+  double f_cori;
+  if (g->d.grid_is_latlon && !p->use_f_plane) f_cori = (2. * p->omega) * sin(pi_180 * lat);
+  else f_cori = (2. * p->omega) * sin(pi_180 * p->lat_ref);
+  const double M = BF(KID_B_MASS, k), T = BF(KID_B_THICKNESS, k);
+  const double D = (p->rho_bergs / RHO_SEAWATER) * T, F = T - D;
+  const double W = BF(KID_B_WIDTH, k), L = BF(KID_B_LENGTH, k);
+  *axn = 0.; *ayn = 0.; *bxn = 0.; *byn = 0.;
+  hi = dmin(hi, D);
+  const double D_hi = dmax(0., D - hi);
+  double groundfrac;
+  if (p->h_to_init_grounding > 0.0) { groundfrac = 1.0 - (od - D) / p->h_to_init_grounding; groundfrac = dmax(groundfrac, 0.0); groundfrac = dmin(groundfrac, 1.0); }
+  else groundfrac = (D > od) ? 1.0 : 0.0;
+  const double c_gnd = (groundfrac > 0.0) ? (p->cdrag_grounding * W * L * groundfrac) / M : 0.0;
+  double uwave = ua - uo, vwave = va - vo;
+  double wmod = uwave * uwave + vwave * vwave;
+  const double ampl = 0.5 * 0.02025 * wmod, Lwavelength = 0.32 * wmod, Lcutoff = 0.125 * Lwavelength, Ltop = 0.25 * Lwavelength;
+  const double Cr = Cr0 * dmin(dmax(0., (L - Lcutoff) / ((Ltop - Lcutoff) + 1.e-30)), 1.);
+  double wave_rad = 0.5 * RHO_SEAWATER / M * Cr * GRAVITY * ampl * dmin(ampl, F) * (2. * W * L) / (W + L);
+  wmod = sqrt(ua * ua + va * va);
+  if (wmod != 0.) { uwave = ua / wmod; vwave = va / wmod; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
+  double dragfrac = 1.0;
+  if (p->iceberg_bonds_on && p->internal_bergs_for_drag) {
+    double N_bonds = 0., N_max = 4.0;
+    if (p->hexagonal_icebergs) N_max = 6.0;
+    for (int s = 0; s < c->bd->count[k]; ++s) {
+      if (p->dem) { if (c->bd->broken[BS(s, k)] != 1) N_bonds = N_bonds + 1.0; } else N_bonds = N_bonds + 1.0;
+    }
+    dragfrac = ((N_max - N_bonds) / N_max);
+  }
+  const double c_ocn = RHO_SEAWATER / M * p->ocean_drag_scale * (0.5 * CD_WV * dragfrac * W * (D_hi) + CD_WH * W * L);
+  const double c_atm = RHO_AIR / M * (0.5 * CD_AV * dragfrac * W * F + CD_AH * W * L);
+  double c_ice = (fabs(hi) == 0.) ? 0. : RHO_ICE / M * (0.5 * CD_IV * dragfrac * W * hi);
+  if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.;
+  if (!RK) { *axn = -GRAVITY * ssh_x + wave_rad * uwave; *ayn = -GRAVITY * ssh_y + wave_rad * vwave; }
+  else { *bxn = -GRAVITY * ssh_x + wave_rad * uwave; *byn = -GRAVITY * ssh_y + wave_rad * vwave; }
+  ia_sum S; memset(&S, 0, sizeof(S));
+  const int ia_on = p->interactive_icebergs_on;
+  if (ia_on) {
+    interactive_force(c, k, &S, uvel0, vvel0, uvel0, vvel0);
+    if (!RK) { *axn = *axn + S.IA_x; *ayn = *ayn + S.IA_y; } else { *bxn = *bxn + S.IA_x; *byn = *byn + S.IA_y; }
+  }
+  if (alpha > 0.) {
+    if (C_N > 0.) { *axn = *axn + f_cori * v_star; *ayn = *ayn - f_cori * u_star; }
+    else { *bxn = *bxn + f_cori * v_star; *byn = *byn - f_cori * u_star; }
+  } else { *bxn = *bxn + f_cori * vvel; *byn = *byn - f_cori * uvel; }
+  double uveln = new_pc ? uvel0 : uvel, vveln = new_pc ? vvel0 : vvel;
+  double us = uvel0, vs = vvel0;
+  for (int itloop = 1; itloop <= 2; ++itloop) {
+    if (itloop == 2) { us = uveln; vs = vveln; }
+    double drag_ocn, drag_atm, drag_ice;
+    if (new_pc) {
+      drag_ocn = c_ocn * 0.5 * (sqrt((uveln - uo) * (uveln - uo) + (vveln - vo) * (vveln - vo)) + sqrt((uvel0 - uo) * (uvel0 - uo) + (vvel0 - vo) * (vvel0 - vo)));
+      drag_atm = c_atm * 0.5 * (sqrt((uveln - ua) * (uveln - ua) + (vveln - va) * (vveln - va)) + sqrt((uvel0 - ua) * (uvel0 - ua) + (vvel0 - va) * (vvel0 - va)));
+      drag_ice = c_ice * 0.5 * (sqrt((uveln - ui) * (uveln - ui) + (vveln - vi) * (vveln - vi)) + sqrt((uvel0 - ui) * (uvel0 - ui) + (vvel0 - vi) * (vvel0 - vi)));
+    } else {
+      us = 0.5 * (uveln + uvel); vs = 0.5 * (vveln + vvel);
+      drag_ocn = c_ocn * sqrt((us - uo) * (us - uo) + (vs - vo) * (vs - vo));
+      drag_atm = c_atm * sqrt((us - ua) * (us - ua) + (vs - va) * (vs - va));
+      drag_ice = c_ice * sqrt((us - ui) * (us - ui) + (vs - vi) * (vs - vi));
+    }
+    const double drag_gnd = c_gnd;
+    double RHS_x = (*axn / 2) + *bxn, RHS_y = (*ayn / 2) + *byn;
+    if (beta > 0.) {
+      RHS_x = RHS_x - drag_ocn * (u_star - uo) - drag_atm * (u_star - ua) - drag_ice * (u_star - ui) - drag_gnd * u_star;
+      RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va) - drag_ice * (v_star - vi) - drag_gnd * v_star;
+    }
+    if (ia_on) {
+      if (itloop > 1) interactive_force(c, k, &S, uvel0, vvel0, us, vs);
+      RHS_x = RHS_x - (((S.P11 * u_star) + (S.P12 * v_star)) - S.Ptu_x);
+      RHS_y = RHS_y - (((S.P21 * u_star) + (S.P22 * v_star)) - S.Ptu_y);
+    }
+    double A11, A12, A21, A22;
+    if (p->only_interactive_forces) {
+      RHS_x = (S.IA_x / 2) - (((S.P11 * u_star) + (S.P12 * v_star)) - S.Ptu_x);
+      RHS_y = (S.IA_y / 2) - (((S.P21 * u_star) + (S.P22 * v_star)) - S.Ptu_y);
+      A11 = 1 + (dt * S.P11); A12 = (dt * S.P12); A21 = (dt * S.P21); A22 = 1 + (dt * S.P22);
+    } else {
+      const double lambda = drag_ocn + drag_atm + drag_ice + drag_gnd;
+      A11 = 1. + beta * dt * lambda; A22 = 1. + beta * dt * lambda;
+      A12 = -alpha * dt * f_cori; A21 = alpha * dt * f_cori;
+      if (C_N > 0.) { A12 = A12 / 2.; A21 = A21 / 2.; }
+      if (ia_on) { A11 = A11 + (dt * S.P11); A12 = A12 + (dt * S.P12); A21 = A21 + (dt * S.P21); A22 = A22 + (dt * S.P22); }
+    }
+    const double detA = 1. / ((A11 * A22) - (A12 * A21));
+    *ax = detA * (A22 * RHS_x - A12 * RHS_y); *ay = detA * (A11 * RHS_y - A21 * RHS_x);
+    uveln = u_star + dt * *ax; vveln = v_star + dt * *ay;
+  }
+  if (p->only_interactive_forces) { *axn = S.IA_x; *ayn = S.IA_y; }
+  else {
+    *axn = 0.; *ayn = 0.;
+    if (!RK) {
+      *axn = -GRAVITY * ssh_x + wave_rad * uwave; *ayn = -GRAVITY * ssh_y + wave_rad * vwave;
+      if (ia_on) { *axn = *axn + S.IA_x; *ayn = *ayn + S.IA_y; }
+    }
+    if (C_N > 0.) { *axn = *axn + f_cori * vveln; *ayn = *ayn - f_cori * uveln; }
+  }
+  *bxn = *ax - (*axn / 2); *byn = *ay - (*ayn / 2);
+  speed_limit(c, i, j, dt, &uveln, &vveln);
+  if (p->override_iceberg_velocities) { *ax = 0.; *ay = 0.; *axn = 0.; *ayn = 0.; *bxn = 0.; *byn = 0.; }
+}
+
+void ko_evolve_icebergs_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars) {
+  mts_ctx ctx, *c = &ctx;
+  ctx_init(c, g, p, b, bd, scalars);
+  const double dt = p->dt, dt_2 = 0.5 * dt;
+  for (int64_t q = 0; q < c->nperm; ++q) { /* first sweep: verlet_stepping IB:7203-7328 */
+    const int64_t k = c->perm[q];
+    if (!(BF(KID_B_STATIC_BERG, k) < 0.5)) continue;
+    const double lonn = BF(KID_B_LON, k), latn = BF(KID_B_LAT, k);
+    double axn = BF(KID_B_AXN, k), ayn = BF(KID_B_AYN, k), bxn = BF(KID_B_BXN, k), byn = BF(KID_B_BYN, k);
+    const double uvel1 = BF(KID_B_UVEL, k), vvel1 = BF(KID_B_VVEL, k);
+    BF(KID_B_UVEL_PREV, k) = uvel1 - dt_2 * bxn; BF(KID_B_VVEL_PREV, k) = vvel1 - dt_2 * byn;
+    const double uvel3 = uvel1 + (dt_2 * axn), vvel3 = vvel1 + (dt_2 * ayn);
+    double ax1, ay1;
+    accel_sts_ia(c, k, BI(KID_BI_INE, k), BI(KID_BI_JNE, k), BF(KID_B_XI, k), BF(KID_B_YJ, k), latn, uvel1, vvel1, uvel1, vvel1, dt,
+                 &ax1, &ay1, &axn, &ayn, &bxn, &byn);
+    double uveln, vveln;
+    if ((latn > 89.) && g->d.grid_is_latlon) {
+      double xdot3, ydot3, xddot1, yddot1;
+      ko_rotvec_to_tang(p, lonn, uvel3, vvel3, &xdot3, &ydot3);
+      ko_rotvec_to_tang(p, lonn, ax1, ay1, &xddot1, &yddot1);
+      ko_rotvec_from_tang(p, lonn, xdot3 + (dt * xddot1), ydot3 + (dt * yddot1), &uveln, &vveln);
+    } else { uveln = uvel3 + (dt * ax1); vveln = vvel3 + (dt * ay1); }
+    if (p->override_iceberg_velocities) { uveln = p->u_override; vveln = p->v_override; }
+    BF(KID_B_AXN, k) = axn; BF(KID_B_AYN, k) = ayn; BF(KID_B_BXN, k) = bxn; BF(KID_B_BYN, k) = byn;
+    BF(KID_B_UVEL, k) = uveln; BF(KID_B_VVEL, k) = vveln;
+  }
+  for (int64_t q = 0; q < c->nperm; ++q) { /* second sweep IB:7180-7198: update_verlet_position IB:7684-7764 + *_old */
+    const int64_t k = c->perm[q];
+    if (!(BF(KID_B_STATIC_BERG, k) < 0.5)) continue;
+    const int on_tang = (BF(KID_B_LAT, k) > 89.) && g->d.grid_is_latlon;
+    const double lon1 = BF(KID_B_LON, k), lat1 = BF(KID_B_LAT, k);
+    double x1 = 0, y1 = 0, dxdl1, dydl;
+    if (on_tang) ko_rotpos_to_tang(p, lon1, lat1, &x1, &y1);
+    ko_meters_to_grid(g, p, lat1, &dxdl1, &dydl);
+    const double uvel1 = BF(KID_B_UVEL, k), vvel1 = BF(KID_B_VVEL, k);
+    const double axn = BF(KID_B_AXN, k), ayn = BF(KID_B_AYN, k), bxn = BF(KID_B_BXN, k), byn = BF(KID_B_BYN, k);
+    const double uvel2 = uvel1 + (dt_2 * axn) + (dt_2 * bxn), vvel2 = vvel1 + (dt_2 * ayn) + (dt_2 * byn);
+    double xdot2 = 0, ydot2 = 0, lonn, latn;
+    if (on_tang) ko_rotvec_to_tang(p, lon1, uvel2, vvel2, &xdot2, &ydot2);
+    const double u2 = uvel2 * dxdl1, v2 = vvel2 * dydl;
+    if (on_tang) ko_rotpos_from_tang(p, x1 + (dt * xdot2), y1 + (dt * ydot2), &lonn, &latn);
+    else { lonn = lon1 + (dt * u2); latn = lat1 + (dt * v2); }
+    int i = BI(KID_BI_INE, k), j = BI(KID_BI_JNE, k), bounced = 0, err = 0;
+    double xi = BF(KID_B_XI, k), yj = BF(KID_B_YJ, k);
+    ko_adjust_index_and_ground(g, p, &lonn, &latn, &i, &j, &xi, &yj, &bounced, &err);
+    if (err) scalars[KID_S_ERROR_COUNT] += 1.;
+    BF(KID_B_LON, k) = lonn; BF(KID_B_LAT, k) = latn; BI(KID_BI_INE, k) = i; BI(KID_BI_JNE, k) = j; BF(KID_B_XI, k) = xi; BF(KID_B_YJ, k) = yj;
+    BF(KID_B_UVEL_OLD, k) = BF(KID_B_UVEL, k); BF(KID_B_VVEL_OLD, k) = BF(KID_B_VVEL, k);
+    BF(KID_B_LON_OLD, k) = lonn; BF(KID_B_LAT_OLD, k) = latn;
+    if (i < g->d.isc || i > g->d.iec || j < g->d.jsc || j > g->d.jec) BI(KID_BI_ALIVE, k) = 0;
+  }
+  ctx_free(c);
+}
+
+/* icebergs_run with interacting bergs under the single-time-step scheme (IB:5409-5512) */
+void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
+                             double *acc, double *out, double *scalars) {
+  const size_t ncell = (size_t)NI(g) * (size_t)NJ(g);
+  const int contact = (p->contact_distance > 0.) || (p->contact_spring_coef != p->spring_coef);
+  memset(acc, 0, (size_t)KID_NACC * ncell * sizeof(double));
+  if (first_visit) {
+    if (contact) ko_set_conglom_ids(g, p, b, bd);                       /* IB:5415-5416 */
+    if (p->iceberg_bonds_on && bd) ko_orig_bond_length(g, p, b, bd);    /* IB:5418 */
+  }
+  if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
+  if (!p->static_icebergs) ko_evolve_icebergs_interactive(g, p, b, bd, scalars);
+  if (contact) ko_set_conglom_ids(g, p, b, bd);                         /* IB:5470-5471 */
+  if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
+  ko_thermodynamics(g, p, b, acc, scalars);
+  ko_create_gridded_icebergs_fields(g, p, b, acc, out);
+  int64_t alive = 0;
+  for (int64_t k = 0; k < b->n; ++k) alive += (b->i32[KID_BI_ALIVE][k] != 0);
+  scalars[KID_S_NBERGS_ALIVE] = (double)alive;
+}
+
 /* set_conglom_ids FW:2601-2646 (+ remove_broken_bonds_between_congloms FW:2689-2731): what transfer_mts_bergs leaves
  * on one PE.  Conglomerates are numbered in traversal order of their first member. */
 void ko_set_conglom_ids(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd) {

@@ -162,6 +162,17 @@ class Oracle:
                                      _dp(self.acc), _dp(self.out), _dp(self.scalars))
         return bergs, bonds
 
+    def run_step_interactive(self, bergs, bonds, nsteps=1):
+        """icebergs_run with interactive_icebergs_on under the single-time-step (Verlet) scheme"""
+        s = self.soa(bergs)
+        bs = self.bond_soa(bonds, len(bergs["lon"]))
+        for _ in range(nsteps):
+            first = 0 if getattr(self, "_visited", False) else 1
+            self._visited = True
+            self.lib.ko_run_step_interactive(C.byref(self.kg), C.byref(self.params), C.byref(s), C.byref(bs), first,
+                                             _dp(self.acc), _dp(self.out), _dp(self.scalars))
+        return bergs, bonds
+
     def step_local(self, bergs):
         s = self.soa(bergs)
         self.lib.ko_step_local(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]), _dp(self.acc), _dp(self.scalars))

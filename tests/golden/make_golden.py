@@ -48,6 +48,19 @@ def cases():
 
     def c4_two_bergs():
         g, p, b, bd = S.config_c4(bump=(150e3, 150e3), two_bergs=True, hexagonal=False, nx=4, ny=6); S.set_diag_all(p); return g, p, b, bd
+    def c4_kid_implicit():
+        g, p, b, bd = S.config_c4(bump=(150e3, 150e3), dem=False, explicit_inner=False, spring_coef=1e-5, sub_steps=20, dt=1800.0); S.set_diag_all(p); return g, p, b, bd
+
+    def sts_kid_contact():
+        g, p, b, bd = S.config_c4(bump=(150e3, 150e3), dem=False, mts=False, contact=True, spring_coef=1e-5, dt=60.0, two_bergs=True, hexagonal=False, nx=4, ny=6)
+        S.set_diag_all(p); return g, p, b, bd
+    extra = {"c4_kid_implicit": (c4_kid_implicit, 6), "sts_kid_contact": (sts_kid_contact, 100)}
+    base = _base(c1_rk4, c1_verlet, c2_small, c3_fl_bits, c3_new_bergs, c4_hex_grounded, c4_two_bergs)
+    base.update(extra)
+    return base
+
+
+def _base(c1_rk4, c1_verlet, c2_small, c3_fl_bits, c3_new_bergs, c4_hex_grounded, c4_two_bergs):
     return {"c1_rk4": (c1_rk4, 144), "c1_verlet": (c1_verlet, 144), "c2_small": (c2_small, 8), "c3_fl_bits": (c3_fl_bits, 40),
             "c3_new_bergs": (c3_new_bergs, 40), "c4_hex_grounded": (c4_hex_grounded, 4), "c4_two_bergs": (c4_two_bergs, 6)}
 

@@ -65,7 +65,10 @@ def run_oracle_mts(grid, params, bergs, bonds, nsteps):
     import oracle_lib
     o = oracle_lib.Oracle(grid, params)
     b, bd = S.copy_bergs(bergs), S.copy_bonds(bonds)
-    o.run_step_mts(b, bd, nsteps)
+    if params.mts:
+        o.run_step_mts(b, bd, nsteps)
+    else:
+        o.run_step_interactive(b, bd, nsteps)   # interacting bergs under the single-time-step scheme
     return (b, o.acc.copy(), o.out.copy(), o.scalars.copy()), bd
 
 

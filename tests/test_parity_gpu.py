@@ -254,7 +254,7 @@ def test_store_environment_off(oracle):
 
 
 @pytest.mark.parametrize("case", ["hex_free", "hex_grounded", "square_free", "two_bergs", "thickness_jitter",
-                                  "kid_explicit", "kid_implicit", "kid_two_bergs"])
+                                  "kid_explicit", "kid_implicit", "kid_two_bergs", "sts_kid", "sts_kid_contact"])
 def test_c4_mts_dem(oracle, case):
     """BASELINE config 4 family at oracle size: bonded DEM elements under MTS velocity Verlet (200 explicit sub-steps
     per step), grounding on a seamount with stress fracture, square and hexagonal packing, a collision between two
@@ -268,10 +268,15 @@ def test_c4_mts_dem(oracle, case):
           "kid_explicit": dict(bump=(150e3, 150e3), dem=False, explicit_inner=True, spring_coef=1e-5, sub_steps=120, dt=3600.0),
           "kid_implicit": dict(bump=(150e3, 150e3), dem=False, explicit_inner=False, spring_coef=1e-5, sub_steps=20, dt=1800.0),
           "kid_two_bergs": dict(bump=(150e3, 150e3), dem=False, explicit_inner=True, spring_coef=1e-5, sub_steps=60, dt=3600.0,
-                                two_bergs=True, hexagonal=False, nx=4, ny=6)}[case]
+                                two_bergs=True, hexagonal=False, nx=4, ny=6),
+          # interacting bergs WITHOUT multiple time stepping (tests/collision_tests/input_KID.nml): springs and implicit
+          # damping inside accel; Stern et al.'s original 3x3 search, then the contact-distance variant with two bergs
+          "sts_kid": dict(bump=(150e3, 150e3), dem=False, mts=False, contact=False, spring_coef=1e-5, dt=60.0),
+          "sts_kid_contact": dict(bump=(150e3, 150e3), dem=False, mts=False, contact=True, spring_coef=1e-5, dt=60.0,
+                                  two_bergs=True, hexagonal=False, nx=4, ny=6)}[case]
     grid, p, b, bd = S.config_c4(**kw)
     S.set_diag_all(p)
-    nsteps = 6
+    nsteps = 6 if p.mts else 100
     ref, refbd = P.run_oracle_mts(grid, p, b, bd, nsteps)
     got, gotbd = P.run_hip_mts(grid, p, b, bd, nsteps)
     rep = P.compare_mts(ref, refbd, got, gotbd, "C4/" + case)

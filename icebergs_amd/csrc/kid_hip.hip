@@ -38,6 +38,7 @@ struct BergPtrs {
   double *f[KID_NB_F64];
   int32_t *i[KID_NB_I32];
   int64_t *id;
+  const double *orient;   // per-berg hexagon orientation from the bonds (IB:4004), or null: initial_orientation
 };
 struct Flags { int has_static, has_fl, store_env, footprint; };  // footprint: area/Uvel/Vvel_on_ocean are read by somebody
 
@@ -267,7 +268,8 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
       const bool act2 = t.alive && !skipped;
       if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
-        spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg, fl.footprint != 0);
+        spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg, fl.footprint != 0,
+                    b.orient ? b.orient[kk] : p.initial_orientation);
       berg_diagnostics(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
     seg_flush(seg, acc, ncell);
@@ -442,6 +444,7 @@ struct kid_handle {
   bool uploaded_nonzero[KID_NB_F64] = {};  // fields that held anything but zeros at the last upload
   bool tail_valid = false;                 // the dead rows are exactly the tail (true between a re-binning and the next launch)
   bool env_ever_stored = false;            // some launch since the last upload wrote berg%uo..od
+  double *d_orient = nullptr;              // bond-derived hexagon orientation per berg (mts / interacting bergs)
   hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   int *d_fl_cursor = nullptr;
@@ -629,6 +632,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_iceberg_counter) (void)hipFree(h->d_iceberg_counter);
   if (h->d_fl_cursor) (void)hipFree(h->d_fl_cursor);
   mts_free(h);
+  if (h->d_orient) (void)hipFree(h->d_orient);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
   if (h->d_redo_count) (void)hipFree(h->d_redo_count);
   if (h->d_redo_list2) (void)hipFree(h->d_redo_list2);
@@ -815,6 +819,7 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
     h->uploaded_nonzero[f] = nz;
   }
   h->tail_valid = false; h->env_ever_stored = false;
+  if (h->bp.orient) { h->bp.orient = nullptr; h->tables_dirty = true; }
   h->n = host->n;
   h->visited = false; h->have_bonds = false;
   KID_HIP(h, hipStreamSynchronize(h->stream));
@@ -1058,6 +1063,7 @@ static int launch_berg(kid_handle *h) {
 extern "C" {
 
 static int mts_depth(kid_handle *h);
+static int bond_orientations(kid_handle *h);
 int kid_evolve_icebergs_mts(kid_handle *h);
 int kid_evolve_icebergs_interactive(kid_handle *h);
 int kid_interp_gridded_fields_to_bergs(kid_handle *h) {
@@ -1163,6 +1169,8 @@ int kid_step_local(kid_handle *h) {
     if (rc) return rc;
     rc = kid_set_conglom_ids(h);                  // transfer_mts_bergs, IB:5459
     if (rc) return rc;
+    rc = bond_orientations(h);
+    if (rc) return rc;
     return launch_berg<PH_THERMO | PH_SPREAD>(h);
   }
   if (p.interactive_icebergs_on) {  // single-time-step scheme with interactions, IB:5409-5512
@@ -1171,6 +1179,8 @@ int kid_step_local(kid_handle *h) {
     if (!p.old_interp_flds_order) { rc = launch_berg<PH_INTERP>(h); if (rc) return rc; }
     if (!p.static_icebergs) { rc = kid_evolve_icebergs_interactive(h); if (rc) return rc; }
     if (contact) { rc = kid_set_conglom_ids(h); if (rc) return rc; }   // IB:5470-5471
+    rc = bond_orientations(h);
+    if (rc) return rc;
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
   }
   if (p.footloose) {  // calving sits between evolve and thermodynamics (IB:5453) and appends bergs: three launches

@@ -455,7 +455,7 @@ __device__ __noinline__ void hexagon_into_quadrants(const kid_params &p, double 
 // ---------------------------------------------------------------------------------------------------------
 template <class CELL>
 __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
-                                            int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg, bool footprint) {
+                                            int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg, bool footprint, double theta) {
   constexpr double rho_sw = 1035.;  // IB:3919 shadows the module's 1025
   const int c = g.idx(i, j);
   const double a_ij = cellv.area();
@@ -497,7 +497,7 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
     const double H = (a_ij > 0) ? dmin(((sqrt(Area / (2. * sqrt(3.))) / sqrt(a_ij))), 1.) : (sqrt(3.) / 2) * (0.49);
     const double origin_x = (x < 0.5) ? 0. : 1., origin_y = (y < 0.5) ? 0. : 1.;
     double Ah, Q1, Q2, Q3, Q4;
-    hexagon_into_quadrants(p, x - origin_x, y - origin_y, H, p.initial_orientation, Ah, Q1, Q2, Q3, Q4);
+    hexagon_into_quadrants(p, x - origin_x, y - origin_y, H, theta, Ah, Q1, Q2, Q3, Q4);  // theta: IB:4003-4004
     Q1 = Q1 / Ah; Q2 = Q2 / Ah; Q3 = Q3 / Ah; Q4 = Q4 / Ah;
     w[4] = 1.;
     if ((x >= 0.5) && (y >= 0.5)) { w[8] = Q1; w[7] = Q2; w[4] = Q3; w[5] = Q4; }

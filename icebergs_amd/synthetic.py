@@ -59,6 +59,7 @@ def default_params():
     p.scale_damping_by_pmag = p.critical_interaction_damping_on = p.tang_crit_int_damp_on = 1
     p.contact_cells_lon = p.contact_cells_lat = 1
     p.max_bonds, p.mts_sub_steps = 6, 1
+    p.rotate_icebergs_for_mass_spreading = 1
     return p
 
 
@@ -349,8 +350,8 @@ def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45
     0.1 m/s onto a Gaussian seamount on the Cartesian grid of tests/dem_ground_frac_test (driver DRV:288-307,
     namelist tests/dem_ground_frac_test/input.nml): MTS velocity Verlet with explicit DEM sub-steps, stress fracture
     on the sub-steps, broken bonds kept for contact, grounding drag on the sub-steps.
-    Differences from that namelist (not built): coastal_drift=0 and no land rows, rotate_icebergs_for_mass_spreading=F,
-    melt rates are computed (set_melt_rates_to_zero=T there)."""
+    Differences from that namelist: coastal_drift=0 and no land rows; melt rates are computed (set_melt_rates_to_zero=T
+    there)."""
     grid = cartesian_grid(ni, nj, gridres, Lx=-1.0)
     d = grid["desc"]
     ii, jj = _ij(d)

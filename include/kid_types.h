@@ -265,8 +265,9 @@ typedef struct kid_params {
   int32_t radius_based_drag;            /* FW:55 */
   int32_t orig_dem_moment_of_inertia;   /* FW:60 */
   int32_t rev_mind;                     /* FW:59 */
+  int32_t rotate_icebergs_for_mass_spreading; /* FW:750: hexagon orientation from the bonds (IB:4004) */
   int32_t diag_mask;                    /* KID_DIAG_* : which `id_*>0` guards are on */
-  int32_t pad1[3];                      /* explicit: no implicit tail padding (Fortran stream I/O moves components) */
+  int32_t pad1[2];                      /* explicit: no implicit tail padding (Fortran stream I/O moves components) */
 } kid_params;
 
 #ifdef __cplusplus

@@ -87,6 +87,7 @@ void ko_default_params(kid_params *p) {
   p->tangental_damping_coef = 2.e-5; p->convergence_tolerance = 1.e-8; p->dem_damping_coef = 0.1; p->poisson = 0.3;
   p->scale_damping_by_pmag = 1; p->critical_interaction_damping_on = 1; p->tang_crit_int_damp_on = 1;
   p->contact_cells_lon = 1; p->contact_cells_lat = 1; p->max_bonds = 6; p->mts_sub_steps = 1;
+  p->rotate_icebergs_for_mass_spreading = 1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1030,6 +1031,12 @@ void ko_hexagon_into_quadrants(double x0, double y0, double H, double theta, dou
 /* ------------------------------------------------------------------------------------------------
  * IB:3959-4085: the nine footprint weights, order yDxL,yDxC,yDxR,yCxL,yCxC,yCxR,yUxL,yUxC,yUxR
  * ---------------------------------------------------------------------------------------------- */
+/* hexagon orientation of the berg being spread: initial_orientation, or the bond-derived value when the caller has
+ * installed a per-berg array (find_orientation_using_iceberg_bonds, IB:4003-4004; oracle/kid_oracle_mts.c) */
+static const double *g_orient = NULL;
+static double g_orient_now = 0.;
+static int g_orient_use = 0;
+void ko_set_orientation(const double *per_berg) { g_orient = per_berg; }
 void ko_spread_weights(const ko_grid *g, const kid_params *p, int i, int j, double x, double y,
                        double Area, double static_berg, double w[9], double *I_fraction_used) {
   double yDxL = 0., yDxC = 0., yDxR = 0., yCxL = 0., yCxR = 0., yUxL = 0., yUxC = 0., yUxR = 0., yCxC = 1.;
@@ -1052,7 +1059,7 @@ void ko_spread_weights(const ko_grid *g, const kid_params *p, int i, int j, doub
     yCxC = 1. - (((yDxL + yUxR) + (yDxR + yUxL)) + ((yCxL + yCxR) + (yDxC + yUxC)));
     fraction_used = 1.;
   } else {
-    double orientation = p->initial_orientation; /* bonds-driven orientation (IB:4004) needs bonds: not in the SoA path */
+    double orientation = g_orient_use ? g_orient_now : p->initial_orientation; /* IB:4003-4004 */
     double H, S, origin_x = 1., origin_y = 1., x0, y0, Ah, Q1, Q2, Q3, Q4;
     if (a_ij > 0) H = dmin(((sqrt(Area / (2. * sqrt(3.))) / sqrt(a_ij))), 1.);
     else H = (sqrt(3.) / 2) * (0.49);
@@ -1395,9 +1402,12 @@ void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_
     const int i = b->i32[KID_BI_INE][k], j = b->i32[KID_BI_JNE][k];
     const double area = GS(g, KID_G_AREA, i, j);
     if (!(area > 0.)) continue;
+    g_orient_use = (g_orient != NULL);
+    if (g_orient) g_orient_now = g_orient[k];
     if ((p->add_weight_to_ocean && !p->time_average_weight) || p->find_melt_using_spread_mass)
       spread_mass(g, p, acc, bs, i, j, bs[KID_B_XI], bs[KID_B_YJ], bs[KID_B_MASS], bs[KID_B_MASS_OF_BITS], bs[KID_B_MASS_SCALING],
                   bs[KID_B_LENGTH] * bs[KID_B_WIDTH], bs[KID_B_THICKNESS], 1);
+    g_orient_use = 0;
     const size_t c = GIDX(g, i, j);
     const double ms = bs[KID_B_MASS_SCALING];
 #define ACC(F, v) acc[(size_t)(F) * ncell + c] = acc[(size_t)(F) * ncell + c] + (v)

@@ -82,6 +82,8 @@ double ko_quad_interp_depth(const ko_grid *g, const kid_params *p, double x, dou
 void ko_run_step_mts(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
                      double *acc, double *out, double *scalars);
 
+void ko_set_orientation(const double *per_berg);
+void ko_find_orientations(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *orientation);
 void ko_evolve_icebergs_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars);
 void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
                              double *acc, double *out, double *scalars);

@@ -1092,6 +1092,53 @@ void ko_evolve_icebergs_interactive(const ko_grid *g, const kid_params *p, kid_b
   ctx_free(c);
 }
 
+/* find_orientation_using_iceberg_bonds IB:3829-3892 for every berg (the value is in radians and is then handed to
+ * the hexagon code, which reads it as degrees -- as the reference does) */
+void ko_find_orientations(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *orientation) {
+  double dummy[KID_NSCALAR] = {0};
+  mts_ctx ctx, *c = &ctx;
+  ctx_init(c, g, p, b, bd, dummy);
+  for (int64_t k = 0; k < b->n; ++k) orientation[k] = p->initial_orientation;
+  for (int64_t q = 0; q < c->nperm; ++q) {
+    const int64_t k = c->perm[q];
+    const int ine = BI(KID_BI_INE, k), jne = BI(KID_BI_JNE, k);
+    if (!((ine > g->d.isd) && (ine < g->d.ied) && (jne >= g->d.jsd) && (jne <= g->d.jed))) continue;
+    double bond_count = 0., Average_angle = 0.;
+    const double lat1 = BF(KID_B_LAT, k), lon1 = BF(KID_B_LON, k);
+    for (int s = 0; s < bd->count[k]; ++s) {
+      const int64_t o = c->other_row[BS(s, k)];
+      if (o < 0) continue;
+      const double lat2 = BF(KID_B_LAT, o), lon2 = BF(KID_B_LON, o);
+      const double dlat = lat2 - lat1, dlon = lon2 - lon1;
+      double dx_dlon, dy_dlat; grid_to_meters(c, 0.5 * (lat1 + lat2), &dx_dlon, &dy_dlat);
+      const double rx = dlon * dx_dlon, ry = dlat * dy_dlat;
+      double angle;
+      if (rx == 0.) angle = p->pi / 2.;
+      else {
+        angle = atan(ry / rx);
+        angle = ((p->pi / 2.) - (orientation[k] * (p->pi / 180.))) - angle;
+        angle = ko_modulo(angle, p->pi / 3.);
+      }
+      bond_count = bond_count + 1.;
+      Average_angle = Average_angle + angle;
+    }
+    if (bond_count > 0) Average_angle = Average_angle / bond_count; else Average_angle = 0.;
+    orientation[k] = ko_modulo(Average_angle, p->pi / 3.);
+  }
+  ctx_free(c);
+}
+static void gridded_with_orientation(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *acc, double *out) {
+  double *orient = NULL;
+  if (p->hexagonal_icebergs && p->iceberg_bonds_on && p->rotate_icebergs_for_mass_spreading && bd) {
+    orient = (double *)malloc(sizeof(double) * (size_t)(b->n > 0 ? b->n : 1));
+    ko_find_orientations(g, p, b, bd, orient);
+    ko_set_orientation(orient);
+  }
+  ko_create_gridded_icebergs_fields(g, p, b, acc, out);
+  ko_set_orientation(NULL);
+  free(orient);
+}
+
 /* icebergs_run with interacting bergs under the single-time-step scheme (IB:5409-5512) */
 void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
                              double *acc, double *out, double *scalars) {
@@ -1107,7 +1154,7 @@ void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa
   if (contact) ko_set_conglom_ids(g, p, b, bd);                         /* IB:5470-5471 */
   if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
   ko_thermodynamics(g, p, b, acc, scalars);
-  ko_create_gridded_icebergs_fields(g, p, b, acc, out);
+  gridded_with_orientation(g, p, b, bd, acc, out);
   int64_t alive = 0;
   for (int64_t k = 0; k < b->n; ++k) alive += (b->i32[KID_BI_ALIVE][k] != 0);
   scalars[KID_S_NBERGS_ALIVE] = (double)alive;
@@ -1240,7 +1287,7 @@ void ko_run_step_mts(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid
   ko_interp_gridded_fields_to_bergs(g, p, b);   /* IB:5458 */
   ko_set_conglom_ids(g, p, b, bd);              /* transfer_mts_bergs, IB:5459 */
   ko_thermodynamics(g, p, b, acc, scalars);
-  ko_create_gridded_icebergs_fields(g, p, b, acc, out);
+  gridded_with_orientation(g, p, b, bd, acc, out);
   int64_t alive = 0;
   for (int64_t k = 0; k < b->n; ++k) alive += (b->i32[KID_BI_ALIVE][k] != 0);
   scalars[KID_S_NBERGS_ALIVE] = (double)alive;

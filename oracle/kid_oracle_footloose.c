@@ -7,6 +7,8 @@
  * One deliberate difference: the "new berg from FL bits" branch (IB:2663-2667) uses l_b of the berg at hand; the
  * reference reuses the local l_b left by whichever berg last went through the calving block.
  * Children are appended to the SoA in traversal order (the reference inserts them into the parent's cell list).
+ * PARITY UNPINNED: the reference holds no vector for this path that can be recomputed here (its footloose regression
+ * numbers need netCDF restarts and FMS's random stream); the restatement is checked by reading and by properties.
  */
 #include "kid_oracle.h"
 #include <stddef.h>

@@ -1,6 +1,6 @@
 """profiles/r01_hbm_traffic.json from the two --pmc passes of exp/run_round.sh (FETCH_SIZE, WRITE_SIZE)."""
 import csv, glob, json, collections, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, grid = {}, []
 for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv"))[0]

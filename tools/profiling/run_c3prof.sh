@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_c3
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python3 $R/tools/profiling/bench_c3.py 1e7 5 > $R/gpurun_out/prof_c3.log 2>&1
+tail -3 $R/gpurun_out/prof_c3.log

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+i=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM"; do
+  i=$((i+1))
+  rm -rf $R/gpurun_out/ph$i
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/ph$i -- python3 $R/tools/profiling/bench_c2_phases.py > $R/gpurun_out/ph$i.log 2>&1
+done

@@ -537,7 +537,7 @@ extern "C" {
 const char *kid_version(void) { return "kid_hip 0.1 (gfx950)"; }
 int64_t kid_sizeof(int which) {
   switch (which) { case 0: return (int64_t)sizeof(kid_params); case 1: return (int64_t)sizeof(kid_grid_desc);
-                   case 2: return (int64_t)sizeof(kid_berg_soa); default: return -1; }
+                   case 2: return (int64_t)sizeof(kid_berg_soa); case 3: return (int64_t)sizeof(kid_bond_soa); default: return -1; }
 }
 const char *kid_last_error(const kid_handle *h) { return h ? h->err.c_str() : "null handle"; }
 

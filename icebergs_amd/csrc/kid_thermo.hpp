@@ -23,8 +23,14 @@ namespace kid {
 //   * seg_flush(): the (slot, run) pairs are dealt to the lanes, each lane sums its run's staged values in lane
 //     order (a fixed order: bitwise reproducible within a wave) and issues ONE atomic for the run.
 // That is ~14x fewer atomics and, unlike a shuffle scan, costs about one LDS write + one LDS read per value.
-constexpr int KID_MAXRUN = 16;  // the hot build shares at most this many cell packets per wave
-constexpr int KID_CHUNK = 12;  // staged values per flush: 6 KB of LDS per wave
+#ifndef KID_EXP_MAXRUN
+#define KID_EXP_MAXRUN 16
+#endif
+#ifndef KID_EXP_CHUNK
+#define KID_EXP_CHUNK 12
+#endif
+constexpr int KID_MAXRUN = KID_EXP_MAXRUN;  // the hot build shares at most this many cell packets per wave
+constexpr int KID_CHUNK = KID_EXP_CHUNK;    // staged values per flush: 6 KB of LDS per wave
 // row stride of the staging block: 64 would put lane r of every row q on the same LDS bank (measured: half of the LDS
 // cycles of the spreading phase were bank conflicts); 66 doubles shifts each row by 4 banks and leaves 2 doubles of
 // slack behind a row for the unrolled, predicated reads of seg_flush_impl

@@ -90,5 +90,6 @@ def load():
     assert lib.kid_sizeof(0) == C.sizeof(T.Params), "kid_params layout mismatch between header and library"
     assert lib.kid_sizeof(1) == C.sizeof(T.GridDesc)
     assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
+    assert lib.kid_sizeof(3) == C.sizeof(T.BondSoA)
     _lib = lib
     return lib

@@ -27,6 +27,7 @@ def test_struct_layouts_match():
     assert lib.kid_sizeof(0) == C.sizeof(T.Params)
     assert lib.kid_sizeof(1) == C.sizeof(T.GridDesc)
     assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
+    assert lib.kid_sizeof(3) == C.sizeof(T.BondSoA)
     assert lib.kid_version().startswith(b"kid_hip")
 
 

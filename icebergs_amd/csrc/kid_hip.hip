@@ -113,13 +113,14 @@ struct Redo { int *list; int *count; long long k0, klen; };   // k0, klen: the r
 #define KID_NUM_VGPR_ATTR
 #endif
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST>
-__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid g, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
+__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid *__restrict__ gtab, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
                                                    double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
   // The parameter block (142 dwords) and the 51 field pointers are read through device-memory tables on demand:
   // as by-value kernel arguments they were all pinned in SGPRs, overflowed the scalar file and came back as
   // thousands of v_readlane spill reloads per wave.
   const kid_params &p = *pp;
   const BergPtrs &b = *bt;
+  const DevGrid &g = *gtab;   // like the other two tables: read on demand, not pinned in ~50 SGPRs for the whole kernel
   constexpr bool SCATTER = (PH & (PH_THERMO | PH_SPREAD)) != 0;
   __shared__ double lds_vals[SCATTER ? KID_SEG_LDS_DOUBLES : 1];   // staging of the per-cell sums (kid_thermo.hpp)
   __shared__ int lds_ints[KID_SEG_LDS_INTS];                         // run tables of the 4 waves
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(256) footloose_kernel(const DevGrid g, const k
 // no host synchronisation, unlike a copy from pageable memory
 __global__ void set_berg_table_kernel(const BergPtrs src, BergPtrs *dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src; }
 __global__ void set_params_kernel(const kid_params src, kid_params *dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src; }
+__global__ void set_grid_kernel(const DevGrid src, DevGrid *dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src; }
 
 #include "kid_mts.inc"
 
@@ -431,6 +433,7 @@ struct kid_handle {
   BergPtrs bp{};
   BergPtrs *d_bp = nullptr;      // device copy of the field-pointer table
   kid_params *d_params = nullptr; // device copy of the parameter block
+  DevGrid *d_grid = nullptr;      // device copy of the grid descriptor (berg_kernel reads it as a table)
   bool tables_dirty = true;
   double *d_spare_f64 = nullptr; unsigned *d_pos = nullptr, *d_flag = nullptr; void *d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
   unsigned long long *d_count = nullptr;
@@ -583,6 +586,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMemset(h->bp.id, 0, (size_t)capacity * sizeof(int64_t)));
   KID_HIP(h, hipMalloc(&h->d_bp, sizeof(BergPtrs)));
   KID_HIP(h, hipMalloc(&h->d_params, sizeof(kid_params)));
+  KID_HIP(h, hipMalloc(&h->d_grid, sizeof(DevGrid)));
   KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
   KID_HIP(h, hipMalloc(&h->d_iceberg_counter, h->ncell * sizeof(int32_t)));
   KID_HIP(h, hipMemset(h->d_iceberg_counter, 0, h->ncell * sizeof(int32_t)));
@@ -626,6 +630,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_count) (void)hipFree(h->d_count);
   if (h->d_bp) (void)hipFree(h->d_bp);
   if (h->d_params) (void)hipFree(h->d_params);
+  if (h->d_grid) (void)hipFree(h->d_grid);
   for (int q = 0; q < 2; ++q) { if (h->d_key[q]) (void)hipFree(h->d_key[q]); if (h->d_idx[q]) (void)hipFree(h->d_idx[q]); }
   if (h->d_sort_tmp) (void)hipFree(h->d_sort_tmp);
   if (h->d_perm_spare) (void)hipFree(h->d_perm_spare);
@@ -1013,7 +1018,6 @@ template <unsigned PH>
 static int launch_berg(kid_handle *h) {
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
   if (h->n == 0) return KID_OK;
-  const DevGrid g = dev_grid(h);
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
@@ -1042,10 +1046,10 @@ static int launch_berg(kid_handle *h) {
     }
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, (const DevGrid *)h->d_grid, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \
     if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(4u * nbp < 2048u ? 4u * nbp : 2048u), dim3(64), 0, gs, g, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(4u * nbp < 2048u ? 4u * nbp : 2048u), dim3(64), 0, gs, (const DevGrid *)h->d_grid, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
     if (nparts == 2) { (void)hipEventRecord(h->evG[part], gs); h->evG_live[part] = true; } else h->evG_live[part] = false;      \
   } while (0)
     if (rk && old) KID_LAUNCH(true, true);
@@ -1094,6 +1098,7 @@ static int refresh_tables(kid_handle *h) {
     if (rc) return rc;
     hipLaunchKernelGGL(set_berg_table_kernel, dim3(1), dim3(64), 0, h->stream, h->bp, h->d_bp);
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(64), 0, h->stream, h->params, h->d_params);
+    hipLaunchKernelGGL(set_grid_kernel, dim3(1), dim3(64), 0, h->stream, dev_grid(h), h->d_grid);
     KID_HIP(h, hipGetLastError());
     h->tables_dirty = false;
   }

@@ -46,6 +46,7 @@ struct DevGrid {
   // the step
   double sin_lat_ref;  // f-plane / Cartesian Coriolis, IB:2043-2047
   double pi_180, r180_pi, dydl, rho_ratio;  // pi/180, 180/pi, (180/pi)/Rearth (IB:462-477), rho_bergs/rho_seawater (IB:2052)
+  double fl_e1;  // exp(pi/4) of the footloose foot length (IB:2538)
   __device__ __forceinline__ int idx(int i, int j) const { return (i - isd) + (j - jsd) * ni; }
 };
 
@@ -575,6 +576,18 @@ __device__ __forceinline__ LatTerms lat_terms_near(const DevGrid &g, const kid_p
 #endif
 }
 
+// footloose beam constants (IB:2538-2547, 3013-3015, 3376-3378): 1/(g rho_sw) and 1/(12 (1 - 0.3**2)) are literals of the
+// source, folded at compile time with the same IEEE operations; x**3 and x**0.25 of the buoyancy length are x*x*x and
+// sqrt(sqrt(x)) (within an ulp of pow; -DKID_EXACT_MATH keeps pow)
+constexpr double FL_LW_C = 1. / (GRAVITY * RHO_SEAWATER), FL_B_C1 = 1. / (12. * (1. - 0.3 * 0.3));
+#ifdef KID_EXACT_MATH
+__device__ __forceinline__ double kid_cube(double x) { return pow(x, 3.); }
+__device__ __forceinline__ double kid_root4(double x) { return pow(x, 0.25); }
+#else
+__device__ __forceinline__ double kid_cube(double x) { return x * x * x; }
+__device__ __forceinline__ double kid_root4(double x) { return sqrt(sqrt(x)); }
+#endif
+
 // per-berg dynamic state carried through one step
 struct BergDyn {
   double lon, lat, uvel, vvel, axn, ayn, bxn, byn, xi, yj, uvel_prev, vvel_prev;
@@ -747,8 +760,8 @@ __device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double 
   }
 }
 __device__ __noinline__ void fl_bits_dimensions(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
-  const double l_c = p.pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = 1. / (12. * (1. - pow(0.3, 2.)));
-  const double l_w = pow(lw_c * p.fl_youngs * B_c * pow(thickness, 3.), 0.25);
+  const double l_c = p.pi / (2. * sqrt(2.));
+  const double l_w = kid_root4(FL_LW_C * p.fl_youngs * FL_B_C1 * kid_cube(thickness));
   const double l_b = l_c * l_w;
   L_fl = 3. * l_b; W_fl = l_b; T_fl = thickness;
   rolling(p, T_fl, W_fl, L_fl);

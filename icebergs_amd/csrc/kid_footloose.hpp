@@ -83,11 +83,11 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
   const int c = g.idx(i, j);
   const double area = g.geo[c].area, ms = b.f[KID_B_MASS_SCALING][q];
   // constants IB:2538-2547
-  const double e1 = exp(0.25 * p.pi), drho = RHO_SEAWATER - p.rho_bergs, sigmay = p.fl_strength * 1000;
+  const double e1 = g.fl_e1, drho = RHO_SEAWATER - p.rho_bergs, sigmay = p.fl_strength * 1000;  // exp(pi/4) from the host
   const double lfootparam = e1 * RHO_SEAWATER * sigmay / (6 * p.rho_bergs * GRAVITY * drho);
-  const double l_c = p.pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = p.fl_youngs / (12. * (1. - kid_pow(0.3, 2.)));
+  const double l_c = p.pi / (2. * sqrt(2.)), lw_c = FL_LW_C, B_c = p.fl_youngs / (12. * (1. - 0.3 * 0.3));
   double T = b.f[KID_B_THICKNESS][q];
-  const double l_w = kid_pow(lw_c * B_c * kid_pow(T, 3.), 0.25);
+  const double l_w = kid_root4(lw_c * B_c * kid_cube(T));
   const double l_b = l_c * l_w;
   double nerr = 0., ncalved = 0.;
   if (!(b.f[KID_B_STATIC_BERG][q] == 1 || b.f[KID_B_FL_K][q] < 0)) {
@@ -108,11 +108,11 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
     if (k > 0) {
       double ds, Ln, Wn;
       if (cc > 0) {
-        ds = 0.5 * ((L + W) - sqrt(kid_pow(L + W, 2.) - 4. * (l_b3 * l_b * k)));
+        ds = 0.5 * ((L + W) - sqrt(((L + W) * (L + W)) - 4. * (l_b3 * l_b * k)));
         Ln = L - ds; Wn = W - ds;
         if (Wn < Wmin) { Ln = Ln * (1 - (Wmin - Wn) / Wmin); Wn = Wmin; }
       } else {
-        ds = k * 3. * kid_pow(l_b, 2.) / W;
+        ds = k * 3. * (l_b * l_b) / W;
         Ln = L - ds; Wn = W;
       }
       const double dA = L * W - Ln * Wn;

@@ -492,6 +492,7 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.sin_lat_ref = sin((h->params.pi / 180.) * h->params.lat_ref);
   g.pi_180 = h->params.pi / 180.; g.r180_pi = 180. / h->params.pi; g.dydl = (180. / h->params.pi) / h->params.Rearth;
   g.rho_ratio = h->params.rho_bergs / RHO_SEAWATER;
+  g.fl_e1 = exp(0.25 * h->params.pi);
   return g;
 }
 // area/Uvel/Vvel_on_ocean (27 planes) are intermediates of spread_area / spread_uvel / spread_vvel / ustar_iceberg

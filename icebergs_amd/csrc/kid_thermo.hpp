@@ -210,8 +210,8 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   }
   double fl_k = b.fl_k;
   if (p.footloose && fl_k >= 0) {  // IB:3011-3028
-    const double l_c = p.pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = 1. / (12. * (1. - kid_pow(0.3, 2.)));
-    const double l_b3 = 3. * l_c * kid_pow(lw_c * p.fl_youngs * B_c * kid_pow(Tn, 3.), 0.25);
+    const double l_c = p.pi / (2. * sqrt(2.));
+    const double l_b3 = 3. * l_c * kid_root4(FL_LW_C * p.fl_youngs * FL_B_C1 * kid_cube(Tn));
     if (L > l_b3) {
       const double fb = Tn * (1. - p.rho_bergs / RHO_SEAWATER), kd = Tn - fb;
       if (W > l_b3) fl_k = fl_k + (dMe / fb - dMv / kd) / p.rho_bergs;

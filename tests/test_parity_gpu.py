@@ -325,3 +325,20 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
             ib.close()
     ref, got = run("plain"), run("pipelined")
     P.compare(ref, got, "pipelined vs plain", params=p)
+
+
+@pytest.mark.parametrize("verlet", [False, True])
+def test_polar_cap(oracle, verlet):
+    """Bergs between 85N and the pole on a lat-lon grid whose top row of cells touches 90N: the tangent-plane branch
+    of both integrators above 89N (IB:7347, 7296), the polar variant of pos_within_cell (FW:6370-6391) with the 5-point
+    point-in-cell test (FW:6226-6296), and bergs that cross the pole row and leave."""
+    grid = S.c2_forcing(S.latlon_grid(ni=360, nj=50, lat0=50.0, dlat=0.8))
+    p = S.default_params()
+    p.dt = 1800.0
+    if verlet:
+        p.Runge_not_Verlet = 0
+    S.set_diag_all(p)
+    b = S.place_bergs(grid, 3000, 7, (3, 358), (44, 50))
+    ref, got = _both(grid, p, b, 24, "fused")
+    P.compare(ref, got, "polar/verlet=%s" % verlet, params=p)
+    assert (ref[0]["lat"][ref[0]["alive"] != 0] > 89.0).sum() > 100

@@ -342,3 +342,28 @@ def test_polar_cap(oracle, verlet):
     ref, got = _both(grid, p, b, 24, "fused")
     P.compare(ref, got, "polar/verlet=%s" % verlet, params=p)
     assert (ref[0]["lat"][ref[0]["alive"] != 0] > 89.0).sum() > 100
+
+
+def test_periodic_seams(oracle):
+    """Bergs hugging the zonal seam of the periodic lat-lon grid (Lx=360: the modulo branches of the point-in-cell
+    tests and of calc_xiyj, FW:6163-6296, 6439-6534) and of a periodic Cartesian grid (Lx=20 km, the regular-grid
+    branch FW:6320-6330); some cross the seam and leave the rank (FW:3024-3041)."""
+    grid, p, _ = S.config_c2(n=10, seed=2)
+    S.set_diag_all(p)
+    east = S.place_bergs(grid, 1500, 31, (357, 360), (8, 192))
+    west = S.place_bergs(grid, 1500, 32, (1, 3), (8, 192))
+    b = {k: (np.concatenate([east[k], west[k]]) if hasattr(east[k], "dtype") else east[k]) for k in east}
+    b["id"] = np.arange(1, len(b["lon"]) + 1, dtype=np.int64)
+    b["uvel"][:1500], b["uvel"][1500:] = 0.4, -0.4          # towards the seam
+    b = S.sort_reference_order(b)
+    ref, got = _both(grid, p, b, 30, "fused")
+    P.compare(ref, got, "seam/latlon", params=p)
+    assert 0 < (ref[0]["alive"] == 0).sum() < len(b["lon"])   # some left, some are still there
+    # Cartesian, periodic in x
+    grid = S.c1_forcing(S.cartesian_grid(20, 20, 1000.0, Lx=20000.0))
+    p = S.default_params()
+    p.dt, p.lat_ref, p.use_f_plane = 600.0, -70.0, 1
+    S.set_diag_all(p)
+    b = S.place_bergs(grid, 400, 33, (1, 20), (4, 17), klass=np.arange(400) % 10)
+    ref, got = _both(grid, p, b, 60, "fused")
+    P.compare(ref, got, "seam/cartesian", params=p)

@@ -464,7 +464,8 @@ struct kid_handle {
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
   bool use_graph = true;
   Flags flags{0, 0, 1, 0};
-  bool have_static = false, have_forcing = false;
+  bool have_static = false, have_forcing = false, have_planes = false;  // have_planes: d_forcing holds all eleven planes
+  double *d_ingest_stage = nullptr; size_t ingest_stage_count = 0; unsigned long long *d_ingest_key = nullptr;  // kid_ingest_forcing
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -541,7 +542,8 @@ extern "C" {
 const char *kid_version(void) { return "kid_hip 0.1 (gfx950)"; }
 int64_t kid_sizeof(int which) {
   switch (which) { case 0: return (int64_t)sizeof(kid_params); case 1: return (int64_t)sizeof(kid_grid_desc);
-                   case 2: return (int64_t)sizeof(kid_berg_soa); case 3: return (int64_t)sizeof(kid_bond_soa); default: return -1; }
+                   case 2: return (int64_t)sizeof(kid_berg_soa); case 3: return (int64_t)sizeof(kid_bond_soa);
+                   case 4: return (int64_t)sizeof(kid_forcing_in); default: return -1; }
 }
 const char *kid_last_error(const kid_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -615,6 +617,8 @@ int kid_destroy(kid_handle *h) {
   (void)hipDeviceSynchronize();
   for (auto &k : h->d_static) if (k) (void)hipFree(k);
   for (auto &k : h->d_forcing) if (k) (void)hipFree(k);
+  if (h->d_ingest_stage) (void)hipFree(h->d_ingest_stage);
+  if (h->d_ingest_key) (void)hipFree(h->d_ingest_key);
   if (h->d_vel) (void)hipFree(h->d_vel);
   if (h->d_trc) (void)hipFree(h->d_trc);
   if (h->d_geo) (void)hipFree(h->d_geo);
@@ -743,6 +747,7 @@ int kid_set_forcing(kid_handle *h, const double *const fields[KID_NFORCING]) {
     KID_HIP(h, hipMemcpyAsync(h->d_forcing[k], fields[k], h->ncell * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
   h->have_forcing = true;
+  { bool all = true; for (int k = 0; k < KID_NFORCING; ++k) all = all && (fields[k] || h->have_planes); h->have_planes = all; }
   const double *none[KID_NFORCING] = {};
   int rc = pack_forcing(h, none);
   if (rc) return rc;
@@ -781,6 +786,8 @@ int kid_step_prepare(kid_handle *h, const double *const fields[KID_NFORCING]) {
   h->acc_prezeroed = true; h->redo_prezeroed = true;
   return KID_OK;
 }
+
+#include "kid_ingest.inc"
 
 int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   if (!h || !host || host->n < 0) return KID_EINVAL;

@@ -19,6 +19,7 @@ module kid_hip_mod
   public :: kid_grid_desc, kid_params, kid_berg_soa
   public :: kid_create, kid_destroy, kid_set_params, kid_sync, kid_set_static_grid, kid_set_forcing
   public :: kid_upload_bergs, kid_download_bergs, kid_num_bergs, kid_compact_bergs
+  public :: kid_forcing_in, kid_ingest_forcing, kid_get_forcing, KID_BGRID_NE, KID_CGRID_NE, KID_AGRID
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
@@ -58,6 +59,19 @@ module kid_hip_mod
     end function
     !> fields(KID_NFORCING): c_loc of grd%uo, grd%vo, ... after the ingest block of icebergs_run (IB:5236-5383)
     integer(c_int) function kid_set_forcing(h, fields) bind(C, name='kid_set_forcing')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      type(c_ptr), intent(in) :: fields(*)
+    end function
+    !> the ingest block of icebergs_run on the device (IB:5236-5383): args holds c_loc of the coupler's uo, vo, ui, vi,
+    !! tauxa, tauya, ssh, sst, cn, hi, sss (c_null_ptr when sss is absent), their extents and staggers
+    integer(c_int) function kid_ingest_forcing(h, args) bind(C, name='kid_ingest_forcing')
+      import :: c_int, c_ptr, kid_forcing_in
+      type(c_ptr), value :: h
+      type(kid_forcing_in), intent(in) :: args
+    end function
+    !> fields(KID_NFORCING): c_loc of grd%uo, grd%vo, ... to be filled for send_data (IB:5529-5548); c_null_ptr skips one
+    integer(c_int) function kid_get_forcing(h, fields) bind(C, name='kid_get_forcing')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
       type(c_ptr), intent(in) :: fields(*)

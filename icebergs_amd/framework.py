@@ -76,6 +76,56 @@ class Icebergs:
             arr[k] = _dp(a)
         self._check(self.lib.kid_set_forcing(self.h, arr), "kid_set_forcing")
 
+    def ingest_forcing(self, args, vel_stagger="B", stress_stagger="B", tau_is_velocity=False, cyclic_x=False, on_device=False):
+        """icebergs_run's ingest block on the device (kid_ingest_forcing, IB:5236-5383).  `args`: dict with uo, vo, ui, vi,
+        tauxa, tauya, ssh, sst, cn, hi and optionally sss -- numpy arrays of shape (n2, n1) holding the Fortran array
+        a(n1, n2), or with on_device (device address, (n2, n1)) pairs."""
+        if on_device:   # resident arrays: the argument block is rebuilt only when an address or a switch changes
+            key = (tuple(sorted((k, int(v[0]), tuple(v[1])) for k, v in args.items() if v is not None)), vel_stagger, stress_stagger, bool(tau_is_velocity), bool(cyclic_x))
+            if getattr(self, "_ingest_key", None) == key:
+                self._check(self.lib.kid_ingest_forcing(self.h, self._ingest_ref), "kid_ingest_forcing")
+                return
+        st = {"B": T.ENUMS["KID_BGRID_NE"], "C": T.ENUMS["KID_CGRID_NE"], "A": T.ENUMS["KID_AGRID"]}
+        fin, keep, shape = T.ForcingIn(), [], {}
+        for name in ("uo", "vo", "ui", "vi", "tauxa", "tauya", "ssh", "sst", "cn", "hi", "sss"):
+            v = args.get(name)
+            if v is None:
+                setattr(fin, name, None)
+                continue
+            if on_device:
+                ptr, shp = v
+                setattr(fin, name, C.cast(C.c_void_p(int(ptr)), C.POINTER(C.c_double)))
+            else:
+                a = np.ascontiguousarray(v, dtype=np.float64)
+                keep.append(a)
+                shp = a.shape
+                setattr(fin, name, _dp(a))
+            shape[name] = shp
+        for name, other in (("uo", "ui"), ("vo", "vi")):
+            assert shape[name] == shape[other], (name, other)
+        d = self.grid["desc"]
+        nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+        for name in ("ssh", "cn", "hi"):
+            assert shape[name] == (njc + 2, nic + 2), (name, shape[name])
+        for name in ("sst", "sss"):
+            assert name not in shape or shape[name] == (njc, nic), (name, shape[name])
+        fin.u_nj, fin.u_ni = shape["uo"]
+        fin.v_nj, fin.v_ni = shape["vo"]
+        fin.taux_nj, fin.taux_ni = shape["tauxa"]
+        fin.tauy_nj, fin.tauy_ni = shape["tauya"]
+        fin.vel_stagger, fin.stress_stagger = st[vel_stagger], st[stress_stagger]
+        fin.tau_is_velocity, fin.cyclic_x, fin.on_device = int(tau_is_velocity), int(cyclic_x), int(on_device)
+        self._check(self.lib.kid_ingest_forcing(self.h, C.byref(fin)), "kid_ingest_forcing")
+        if on_device:
+            self._ingest_key, self._ingest_fin, self._ingest_ref = key, fin, C.byref(fin)
+
+    def get_forcing(self):
+        """grd%uo .. grd%hi as the handle holds them (after set_forcing or ingest_forcing)"""
+        out = {name: np.empty((self.nj, self.ni)) for name in T.FORCING_NAMES}
+        arr = (C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"])(*[_dp(out[name]) for name in T.FORCING_NAMES])
+        self._check(self.lib.kid_get_forcing(self.h, arr), "kid_get_forcing")
+        return out
+
     def set_forcing_device(self, dev_ptrs):
         """dev_ptrs: KID_NFORCING device addresses (0 keeps a plane); asynchronous on the handle's stream."""
         arr = (C.c_void_p * T.ENUMS["KID_NFORCING"])(*[C.c_void_p(int(x)) if x else None for x in dev_ptrs])

@@ -20,6 +20,7 @@ SYMBOLS = [
     "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
     "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
+    "kid_ingest_forcing", "kid_get_forcing",
 ]
 
 
@@ -43,6 +44,9 @@ def load():
     if not os.path.exists(SO_PATH):
         raise KidError("libkid_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                        "there is no CPU fallback")
+    # torch ships its own libamdhip64: whichever HIP runtime a process loads second finds no GPUs.  Python callers use
+    # torch for device memory and RCCL, so let its runtime load first; libkid_hip.so then binds to the same SONAME.
+    import torch  # noqa: F401
     lib = C.CDLL(SO_PATH)
     H = C.c_void_p
     dp = C.POINTER(C.c_double)
@@ -59,6 +63,8 @@ def load():
     lib.kid_set_static_grid.argtypes = [H, C.POINTER(dp)]
     lib.kid_set_forcing.argtypes = [H, C.POINTER(dp)]
     lib.kid_set_forcing_device.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.kid_ingest_forcing.argtypes = [H, C.POINTER(T.ForcingIn)]
+    lib.kid_get_forcing.argtypes = [H, C.POINTER(dp)]
     lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_step_prepare.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.kid_set_side_stream.argtypes = [H, C.c_void_p, C.c_int]
@@ -91,5 +97,6 @@ def load():
     assert lib.kid_sizeof(1) == C.sizeof(T.GridDesc)
     assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
     assert lib.kid_sizeof(3) == C.sizeof(T.BondSoA)
+    assert lib.kid_sizeof(4) == C.sizeof(T.ForcingIn)
     _lib = lib
     return lib

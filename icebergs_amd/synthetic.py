@@ -155,6 +155,38 @@ def c2_forcing(grid):
     return grid
 
 
+def coupler_forcing(grid, seed=0, vel_stagger="B", stress_stagger="B", symmetric=False, kelvin=False, sss=True, nans=True):
+    """Synthetic arguments of icebergs_run (icebergs.F90:5074-5096) for a grid: what the coupler hands over BEFORE the
+    ingest block, with the extents each stagger implies (symmetric memory adds the extra C-grid row / column).
+    Arrays are (n2, n1) numpy = Fortran a(n1, n2)."""
+    d = grid["desc"]
+    nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+    rng = np.random.default_rng(seed)
+    f = lambda n2, n1, s: rng.normal(0.0, s, (n2, n1))
+    if vel_stagger == "B":
+        ushape = vshape = (njc + 2, nic + 2)
+    else:   # C-grid: data-domain sized arrays, one more u column / v row with symmetric memory (IB:5245)
+        ushape = (njc + 2, nic + 2 + (1 if symmetric else 0))
+        vshape = (njc + 2 + (1 if symmetric else 0), nic + 2)
+    if stress_stagger == "C":
+        txshape = (njc + 2, nic + 2 + (1 if symmetric else 0))
+        tyshape = (njc + 2 + (1 if symmetric else 0), nic + 2)
+    else:
+        txshape = tyshape = (njc, nic)
+    a = {"uo": f(*ushape, 0.3), "ui": f(*ushape, 0.1), "vo": f(*vshape, 0.3), "vi": f(*vshape, 0.1),
+         "tauxa": f(*txshape, 0.2), "tauya": f(*tyshape, 0.2),
+         "ssh": f(njc + 2, nic + 2, 0.5), "cn": rng.uniform(0, 1, (njc + 2, nic + 2)), "hi": rng.uniform(0, 2, (njc + 2, nic + 2)),
+         "sst": rng.uniform(-1.5, 25.0, (njc, nic)) + (273.15 if kelvin else 0.0)}
+    if sss:
+        a["sss"] = rng.uniform(30.0, 36.0, (njc, nic))
+    if nans:   # what the scrub (IB:5373-5382) is there for; a zero stress exercises the cddvmod == 0 branch
+        for name in ("uo", "vi", "cn", "tauxa"):
+            a[name][rng.integers(1, a[name].shape[0] - 1), rng.integers(1, a[name].shape[1] - 1)] = np.nan
+        a["tauxa"][2, 3] = 0.0
+        a["tauya"][2, 3] = 0.0
+    return a
+
+
 def empty_bergs(n):
     b = {name: np.zeros(n) for name in T.BERG_F64_NAMES}
     for name in T.BERG_I32_NAMES:

@@ -41,6 +41,7 @@ def _parse_struct(src, name, consts):
         decl = decl.strip()
         if not decl:
             continue
+        decl = re.sub(r"^const\s+", "", decl)
         mm = re.match(r"(double|int32_t|int64_t)\s*(\*?)\s*(.*)", decl)
         base, ptr, rest = mm.group(1), mm.group(2), mm.group(3)
         for var in rest.split(","):
@@ -73,6 +74,10 @@ class Params(C.Structure):
 
 class BergSoA(C.Structure):
     _fields_ = _parse_struct(_src, "kid_berg_soa", ENUMS)
+
+
+class ForcingIn(C.Structure):
+    _fields_ = _parse_struct(_src, "kid_forcing_in", ENUMS)
 
 
 class BondSoA(C.Structure):

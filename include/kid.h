@@ -10,6 +10,7 @@
  *   -----------------------------------------------------  --------------------------------------------
  *   ice_bergs_framework_init, grid copy   FW:1021-1094     kid_create + kid_set_static_grid
  *   forcing ingest result (grd%uo ... )   IB:5236-5383     kid_set_forcing
+ *   the forcing ingest block itself       IB:5236-5383     kid_ingest_forcing (+ kid_get_forcing for send_data)
  *   accumulator zeroing                   IB:5125-5156     kid_zero_accumulators
  *   interp_gridded_fields_to_bergs        IB:5423, 5473    kid_interp_gridded_fields_to_bergs
  *   evolve_icebergs                       IB:5433          kid_evolve_icebergs
@@ -62,7 +63,7 @@ int kid_set_side_stream(kid_handle *h, void *side_stream, int enable);
 int kid_sync(kid_handle *h);
 const char *kid_last_error(const kid_handle *h);
 const char *kid_version(void);
-int64_t kid_sizeof(int which); /* 0 kid_params, 1 kid_grid_desc, 2 kid_berg_soa: ABI layout check */
+int64_t kid_sizeof(int which); /* 0 kid_params, 1 kid_grid_desc, 2 kid_berg_soa, 3 kid_bond_soa, 4 kid_forcing_in: ABI layout check */
 
 /* ---- grid and forcing (host pointers; KID_G_* / KID_F_* order) ---- */
 int kid_set_static_grid(kid_handle *h, const double *const fields[KID_NGRID_STATIC]);
@@ -86,6 +87,18 @@ int kid_set_resort_interval(kid_handle *h, int steps);
  * switch it off (on = 0) and save 13 stores per berg per step.  Refused (KID_EINVAL at launch) when the stored
  * environment is an input, i.e. .not.old_interp_flds_order.  Default on. */
 int kid_set_store_environment(kid_handle *h, int on);
+
+/* Forcing ingest on the device: the block of icebergs_run that builds grd%uo .. grd%hi from the
+ * coupler's arguments, IB:5236-5383 + invert_tau_for_du IB:8272-8296: B/C-grid velocities, B/C/A-grid wind stress,
+ * stress -> velocity difference, the Kelvin test on sst, sss = -1 when absent, land / NaN scrub.  One rank owns the
+ * whole domain, so mpp_update_domains reduces to the zonal wrap of the halo columns (in->cyclic_x) or to nothing.
+ * Replaces the host-side ingest + kid_set_forcing.  Host arrays are staged and the call returns when they may be
+ * reused; with in->on_device nothing is copied and the call is asynchronous on the handle's stream.
+ * add_iceberg_thickness_to_SSH (IB:5330-5337) stays with the host. */
+int kid_ingest_forcing(kid_handle *h, const kid_forcing_in *in);
+/* grd%uo .. grd%hi as the handle holds them (KID_F_* order, data-domain planes, NULL entries skipped): what the
+ * reference hands to send_data for id_uo, id_vo, ... (IB:5529-5548).  Needs kid_set_forcing or kid_ingest_forcing. */
+int kid_get_forcing(kid_handle *h, double *const fields[KID_NFORCING]);
 
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */

@@ -46,6 +46,25 @@ enum {
   KID_NFORCING
 };
 
+/* ---- forcing ingest: the arguments of icebergs_run as the coupler passes them (IB:5074-5096), turned
+ * into the grd%* planes above by kid_ingest_forcing (IB:5236-5383).  Arrays are column-major, first index fastest.
+ * Extents: uo, ui are u_ni x u_nj and vo, vi are v_ni x v_nj (B-grid: both (isc-1:iec+1, jsc-1:jec+1); C-grid:
+ * symmetric memory or not, the offsets follow IB:5246-5249); tauxa is taux_ni x taux_nj, tauya tauy_ni x tauy_nj;
+ * ssh, cn, hi cover (isc-1:iec+1, jsc-1:jec+1); sst, sss cover the computational domain; sss may be NULL
+ * (grd%sss = -1, IB:5357). ---- */
+enum { KID_BGRID_NE = 0, KID_CGRID_NE = 1, KID_AGRID = 2 };   /* mpp_parameter_mod staggers the reference accepts */
+typedef struct kid_forcing_in {
+  const double *uo, *vo, *ui, *vi;
+  const double *tauxa, *tauya;
+  const double *ssh, *sst, *cn, *hi, *sss;
+  int32_t u_ni, u_nj, v_ni, v_nj;           /* size(uo,1), size(uo,2), size(vo,1), size(vo,2) */
+  int32_t taux_ni, taux_nj, tauy_ni, tauy_nj;
+  int32_t vel_stagger, stress_stagger;      /* stagger / stress_stagger arguments, IB:5090-5091 */
+  int32_t tau_is_velocity;                  /* bergs%tau_is_velocity, IB:5321 */
+  int32_t cyclic_x;                         /* the domain is zonally cyclic: halo columns wrap (mpp_update_domains on one rank) */
+  int32_t on_device, pad;                   /* pointers are device addresses (no staging copy) */
+} kid_forcing_in;
+
 /* ---- per-berg fp64 fields (type iceberg, FW:294-343) ---- */
 enum {
   KID_B_LON = 0, KID_B_LAT, KID_B_UVEL, KID_B_VVEL,

@@ -87,6 +87,8 @@ void ko_find_orientations(const ko_grid *g, const kid_params *p, kid_berg_soa *b
 void ko_evolve_icebergs_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars);
 void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
                              double *acc, double *out, double *scalars);
+/* forcing ingest (oracle/kid_oracle_ingest.c), IB:5236-5383; returns non-zero on inconsistent extents / staggers */
+int ko_ingest_forcing(const ko_grid *g, const kid_forcing_in *in, double *const out[KID_NFORCING]);
 void ko_default_params(kid_params *p);
 int64_t ko_sizeof(int which);
 

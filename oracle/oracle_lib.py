@@ -62,6 +62,8 @@ def load():
                                       C.POINTER(d), C.POINTER(d)]
     lib.ko_default_params.restype = None
     lib.ko_default_params.argtypes = [C.POINTER(T.Params)]
+    lib.ko_ingest_forcing.restype = C.c_int
+    lib.ko_ingest_forcing.argtypes = [C.POINTER(KoGrid), C.POINTER(T.ForcingIn), C.POINTER(C.POINTER(d))]
     for name in ("ko_interp_gridded_fields_to_bergs",):
         getattr(lib, name).restype = None
         getattr(lib, name).argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA)]
@@ -119,6 +121,30 @@ class Oracle:
             a = np.ascontiguousarray(forcing[name], dtype=np.float64)
             self._fkeep.append(a)
             self.kg.forc[k] = _dp(a)
+
+    def ingest_forcing(self, args, vel_stagger="B", stress_stagger="B", tau_is_velocity=False, cyclic_x=False, planes=None):
+        """ko_ingest_forcing (icebergs.F90:5236-5383) on the coupler arguments `args` (numpy arrays (n2, n1) = Fortran a(n1, n2));
+        `planes`: the grd%* planes before the call (default: zeros); returns the planes after it, or None on refused extents"""
+        st = {"B": T.ENUMS["KID_BGRID_NE"], "C": T.ENUMS["KID_CGRID_NE"], "A": T.ENUMS["KID_AGRID"]}
+        fin, keep = T.ForcingIn(), []
+        for name in ("uo", "vo", "ui", "vi", "tauxa", "tauya", "ssh", "sst", "cn", "hi", "sss"):
+            v = args.get(name)
+            if v is None:
+                continue
+            a = np.ascontiguousarray(v, dtype=np.float64)
+            keep.append(a)
+            setattr(fin, name, _dp(a))
+        fin.u_nj, fin.u_ni = args["uo"].shape
+        fin.v_nj, fin.v_ni = args["vo"].shape
+        fin.taux_nj, fin.taux_ni = args["tauxa"].shape
+        fin.tauy_nj, fin.tauy_ni = args["tauya"].shape
+        fin.vel_stagger, fin.stress_stagger = st[vel_stagger], st[stress_stagger]
+        fin.tau_is_velocity, fin.cyclic_x = int(tau_is_velocity), int(cyclic_x)
+        out = {name: (np.zeros((self.nj, self.ni)) if planes is None else np.array(planes[name], dtype=np.float64, order="C"))
+               for name in T.FORCING_NAMES}
+        arr = (C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"])(*[_dp(out[name]) for name in T.FORCING_NAMES])
+        rc = self.lib.ko_ingest_forcing(C.byref(self.kg), C.byref(fin), arr)
+        return out if rc == 0 else None
 
     @staticmethod
     def soa(bergs):

@@ -465,6 +465,8 @@ struct kid_handle {
   bool use_graph = true;
   Flags flags{0, 0, 1, 0};
   bool have_static = false, have_forcing = false, have_planes = false;  // have_planes: d_forcing holds all eleven planes
+  double *d_calv_state = nullptr, *d_calv_scal = nullptr, *d_calv_part = nullptr; unsigned char *d_calv_flag = nullptr; int2 *d_calv_list = nullptr; double *calv_host = nullptr; kid_calving_params calv_params{};  // kid_calving (kid_calving.inc)
+  bool calving_on = false, calving_first_call = true, rmean_init = false, rmean_hflx_init = false;
   double *d_ingest_stage = nullptr; size_t ingest_stage_count = 0; unsigned long long *d_ingest_key = nullptr;  // kid_ingest_forcing
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -543,7 +545,8 @@ const char *kid_version(void) { return "kid_hip 0.1 (gfx950)"; }
 int64_t kid_sizeof(int which) {
   switch (which) { case 0: return (int64_t)sizeof(kid_params); case 1: return (int64_t)sizeof(kid_grid_desc);
                    case 2: return (int64_t)sizeof(kid_berg_soa); case 3: return (int64_t)sizeof(kid_bond_soa);
-                   case 4: return (int64_t)sizeof(kid_forcing_in); default: return -1; }
+                   case 4: return (int64_t)sizeof(kid_forcing_in);
+                   case 5: return (int64_t)sizeof(kid_calving_params); case 6: return (int64_t)sizeof(kid_calving_in); default: return -1; }
 }
 const char *kid_last_error(const kid_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -618,6 +621,12 @@ int kid_destroy(kid_handle *h) {
   for (auto &k : h->d_static) if (k) (void)hipFree(k);
   for (auto &k : h->d_forcing) if (k) (void)hipFree(k);
   if (h->d_ingest_stage) (void)hipFree(h->d_ingest_stage);
+  if (h->d_calv_state) (void)hipFree(h->d_calv_state);
+  if (h->d_calv_scal) (void)hipFree(h->d_calv_scal);
+  if (h->d_calv_part) (void)hipFree(h->d_calv_part);
+  if (h->d_calv_flag) (void)hipFree(h->d_calv_flag);
+  if (h->d_calv_list) (void)hipFree(h->d_calv_list);
+  if (h->calv_host) (void)hipHostFree(h->calv_host);
   if (h->d_ingest_key) (void)hipFree(h->d_ingest_key);
   if (h->d_vel) (void)hipFree(h->d_vel);
   if (h->d_trc) (void)hipFree(h->d_trc);
@@ -925,7 +934,7 @@ int kid_compact_bergs(kid_handle *h) {
 // append bergs (footloose) or the MTS path writes everything.
 static bool field_never_written(const kid_handle *h, int f) {
   const kid_params &p = h->params;
-  if (p.footloose || p.mts) return false;
+  if (p.footloose || p.mts || h->calving_on) return false;
   switch (f) {
     case KID_B_AXN_FAST: case KID_B_AYN_FAST: case KID_B_BXN_FAST: case KID_B_BYN_FAST: case KID_B_ANG_VEL: case KID_B_ANG_ACCEL: case KID_B_ROT:
     case KID_B_UVEL_OLD: case KID_B_VVEL_OLD: case KID_B_LON_OLD: case KID_B_LAT_OLD:
@@ -1167,6 +1176,7 @@ int kid_create_gridded_icebergs_fields(kid_handle *h) {
 }
 
 #include "kid_mts_host.inc"
+#include "kid_calving.inc"
 
 int kid_step_local(kid_handle *h) {
   if (!h) return KID_EINVAL;

@@ -20,6 +20,8 @@ module kid_hip_mod
   public :: kid_create, kid_destroy, kid_set_params, kid_sync, kid_set_static_grid, kid_set_forcing
   public :: kid_upload_bergs, kid_download_bergs, kid_num_bergs, kid_compact_bergs
   public :: kid_forcing_in, kid_ingest_forcing, kid_get_forcing, KID_BGRID_NE, KID_CGRID_NE, KID_AGRID
+  public :: kid_calving_params, kid_calving_in, kid_set_calving_params, kid_set_calving_state, kid_get_calving_state
+  public :: kid_calving, kid_get_calving, KID_NCALV_SCALARS, KID_NCLASSES
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
@@ -75,6 +77,34 @@ module kid_hip_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: h
       type(c_ptr), intent(in) :: fields(*)
+    end function
+    !> the per-hemisphere calving tables of ice_bergs_framework_init (FW:1534-1551), tau_calving, bergs%restarted
+    integer(c_int) function kid_set_calving_params(h, cp) bind(C, name='kid_set_calving_params')
+      import :: c_int, c_ptr, kid_calving_params
+      type(c_ptr), value :: h
+      type(kid_calving_params), intent(in) :: cp
+    end function
+    !> read_restart_calving: c_loc of grd%stored_ice, grd%stored_heat, grd%rmean_calving, grd%rmean_calving_hflx (c_null_ptr keeps)
+    integer(c_int) function kid_set_calving_state(h, stored_ice, stored_heat, rmean_calving, rmean_calving_hflx) &
+        bind(C, name='kid_set_calving_state')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, stored_ice, stored_heat, rmean_calving, rmean_calving_hflx
+    end function
+    integer(c_int) function kid_get_calving_state(h, stored_ice, stored_heat, rmean_calving, rmean_calving_hflx, real_calving) &
+        bind(C, name='kid_get_calving_state')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, stored_ice, stored_heat, rmean_calving, rmean_calving_hflx, real_calving
+    end function
+    !> IB:5203-5231 + accumulate_calving (IB:5388) + calve_icebergs (IB:5403); scalars(KID_NCALV_SCALARS) in KID_CS_* order
+    integer(c_int) function kid_calving(h, args, scalars) bind(C, name='kid_calving')
+      import :: c_int, c_ptr, c_double, kid_calving_in
+      type(c_ptr), value :: h
+      type(kid_calving_in), intent(in) :: args
+      real(c_double), intent(out) :: scalars(*)
+    end function
+    integer(c_int) function kid_get_calving(h, calving, calving_hflx) bind(C, name='kid_get_calving')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, calving, calving_hflx
     end function
     integer(c_int) function kid_upload_bergs(h, soa) bind(C, name='kid_upload_bergs')
       import :: c_int, c_ptr, kid_berg_soa

@@ -126,6 +126,45 @@ class Icebergs:
         self._check(self.lib.kid_get_forcing(self.h, arr), "kid_get_forcing")
         return out
 
+    # ---- calving source (IB:5203-5231, accumulate_calving IB:6153, calve_icebergs IB:6225) ----
+    def set_calving_params(self, cp):
+        self._calv_params = cp
+        self._check(self.lib.kid_set_calving_params(self.h, C.byref(cp)), "kid_set_calving_params")
+
+    def set_calving_state(self, stored_ice=None, stored_heat=None, rmean_calving=None, rmean_calving_hflx=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (stored_ice, stored_heat, rmean_calving, rmean_calving_hflx)]
+        if arrs[0] is not None:
+            assert arrs[0].shape == (T.ENUMS["KID_NCLASSES"], self.nj, self.ni)
+        self._check(self.lib.kid_set_calving_state(self.h, *[None if a is None else _dp(a) for a in arrs]), "kid_set_calving_state")
+
+    def get_calving_state(self):
+        nk = T.ENUMS["KID_NCLASSES"]
+        out = {"stored_ice": np.empty((nk, self.nj, self.ni)), "stored_heat": np.empty((self.nj, self.ni)),
+               "rmean_calving": np.empty((self.nj, self.ni)), "rmean_calving_hflx": np.empty((self.nj, self.ni)),
+               "real_calving": np.empty((nk, self.nj, self.ni)), "calving": np.empty((self.nj, self.ni)), "calving_hflx": np.empty((self.nj, self.ni))}
+        self._check(self.lib.kid_get_calving_state(self.h, _dp(out["stored_ice"]), _dp(out["stored_heat"]), _dp(out["rmean_calving"]),
+                                                   _dp(out["rmean_calving_hflx"]), _dp(out["real_calving"])), "kid_get_calving_state")
+        self._check(self.lib.kid_get_calving(self.h, _dp(out["calving"]), _dp(out["calving_hflx"])), "kid_get_calving")
+        return out
+
+    def calving(self, calving, calving_hflx, on_device=False):
+        """kid_calving; arrays cover (isc:iec, jsc:jec) as (njc, nic) numpy, or device addresses with on_device.
+        Returns the KID_CS_* scalar increments."""
+        cin = T.CalvingIn()
+        if on_device:
+            cin.calving = C.cast(C.c_void_p(int(calving)), C.POINTER(C.c_double))
+            cin.calving_hflx = C.cast(C.c_void_p(int(calving_hflx)), C.POINTER(C.c_double))
+        else:
+            d = self.grid["desc"]
+            a = np.ascontiguousarray(calving, dtype=np.float64)
+            b = np.ascontiguousarray(calving_hflx, dtype=np.float64)
+            assert a.shape == b.shape == (d.jec - d.jsc + 1, d.iec - d.isc + 1), a.shape
+            cin.calving, cin.calving_hflx = _dp(a), _dp(b)
+        cin.on_device = int(on_device)
+        scal = np.zeros(T.ENUMS["KID_NCALV_SCALARS"])
+        self._check(self.lib.kid_calving(self.h, C.byref(cin), _dp(scal)), "kid_calving")
+        return scal
+
     def set_forcing_device(self, dev_ptrs):
         """dev_ptrs: KID_NFORCING device addresses (0 keeps a plane); asynchronous on the handle's stream."""
         arr = (C.c_void_p * T.ENUMS["KID_NFORCING"])(*[C.c_void_p(int(x)) if x else None for x in dev_ptrs])

@@ -21,6 +21,7 @@ SYMBOLS = [
     "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
     "kid_ingest_forcing", "kid_get_forcing",
+    "kid_set_calving_params", "kid_set_calving_state", "kid_get_calving_state", "kid_calving", "kid_get_calving",
 ]
 
 
@@ -65,6 +66,11 @@ def load():
     lib.kid_set_forcing_device.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.kid_ingest_forcing.argtypes = [H, C.POINTER(T.ForcingIn)]
     lib.kid_get_forcing.argtypes = [H, C.POINTER(dp)]
+    lib.kid_set_calving_params.argtypes = [H, C.POINTER(T.CalvingParams)]
+    lib.kid_set_calving_state.argtypes = [H, dp, dp, dp, dp]
+    lib.kid_get_calving_state.argtypes = [H, dp, dp, dp, dp, dp]
+    lib.kid_calving.argtypes = [H, C.POINTER(T.CalvingIn), dp]
+    lib.kid_get_calving.argtypes = [H, dp, dp]
     lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_step_prepare.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.kid_set_side_stream.argtypes = [H, C.c_void_p, C.c_int]
@@ -98,5 +104,6 @@ def load():
     assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
     assert lib.kid_sizeof(3) == C.sizeof(T.BondSoA)
     assert lib.kid_sizeof(4) == C.sizeof(T.ForcingIn)
+    assert lib.kid_sizeof(5) == C.sizeof(T.CalvingParams) and lib.kid_sizeof(6) == C.sizeof(T.CalvingIn)
     _lib = lib
     return lib

@@ -155,6 +155,42 @@ def c2_forcing(grid):
     return grid
 
 
+def calving_params(p, LoW_ratio=1.5, tau_calving=0.0, restarted=False):
+    """kid_calving_params with the namelist defaults (icebergs_framework.F90:706, 788-796) and the derived initial
+    width / length of FW:1540-1541, 1549-1550."""
+    cp = T.CalvingParams()
+    dist_s = (0.24, 0.12, 0.15, 0.18, 0.12, 0.07, 0.03, 0.03, 0.03, 0.02)
+    dist_n = (0.14, 0.15, 0.20, 0.15, 0.08, 0.07, 0.05, 0.05, 0.05, 0.05)
+    scal_s = (2000, 200, 50, 20, 10, 5, 2, 1, 1, 1)
+    scal_n = (200, 50, 25, 13, 8, 5, 2, 1, 1, 1)
+    thick_s = (40., 67., 133., 175., 250., 250., 250., 250., 250., 250.)
+    thick_n = (80.4, 159.5, 240., 320., 360., 360., 360., 360., 360., 360.)
+    for k in range(10):
+        cp.distribution_s[k], cp.distribution_n[k] = dist_s[k], dist_n[k]
+        cp.mass_scaling_s[k], cp.mass_scaling_n[k] = scal_s[k], scal_n[k]
+        cp.initial_thickness_s[k], cp.initial_thickness_n[k] = thick_s[k], thick_n[k]
+        cp.initial_width_s[k] = np.sqrt(p.initial_mass_s[k] / (LoW_ratio * p.rho_bergs * thick_s[k]))
+        cp.initial_width_n[k] = np.sqrt(p.initial_mass_n[k] / (LoW_ratio * p.rho_bergs * thick_n[k]))
+        cp.initial_length_s[k] = LoW_ratio * cp.initial_width_s[k]
+        cp.initial_length_n[k] = LoW_ratio * cp.initial_width_n[k]
+    cp.tau_calving, cp.restarted = tau_calving, int(restarted)
+    return cp
+
+
+def coupler_calving(grid, seed=0, frac=0.05, buckets=1.5, dt=1800.0):
+    """Synthetic calving / calving_hflx arguments of icebergs_run (kg/m2/s, W/m2) over (isc:iec, jsc:jec): a fraction
+    `frac` of the cells calves, each delivering up to `buckets` class-1 buckets (8.8e7 kg x 2000 / 0.24) per step of
+    length dt, so that buckets of several classes overflow within a few steps."""
+    d = grid["desc"]
+    nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+    area = grid["static"]["area"][d.jsc - d.jsd:d.jec - d.jsd + 1, d.isc - d.isd:d.iec - d.isd + 1]
+    rng = np.random.default_rng(seed)
+    on = rng.random((njc, nic)) < frac
+    calving = np.where(on, rng.uniform(0.2, 1.0, (njc, nic)) * buckets * (8.8e7 * 2000 / 0.24) / (dt * area), 0.0)
+    hflx = np.where(on, -rng.uniform(0.5, 1.5, (njc, nic)) * calving * 2.0e4, 0.0)   # cold ice: a negative heat flux
+    return calving, hflx
+
+
 def coupler_forcing(grid, seed=0, vel_stagger="B", stress_stagger="B", symmetric=False, kelvin=False, sss=True, nans=True):
     """Synthetic arguments of icebergs_run (icebergs.F90:5074-5096) for a grid: what the coupler hands over BEFORE the
     ingest block, with the extents each stagger implies (symmetric memory adds the extra C-grid row / column).

@@ -80,6 +80,14 @@ class ForcingIn(C.Structure):
     _fields_ = _parse_struct(_src, "kid_forcing_in", ENUMS)
 
 
+class CalvingParams(C.Structure):
+    _fields_ = _parse_struct(_src, "kid_calving_params", ENUMS)
+
+
+class CalvingIn(C.Structure):
+    _fields_ = _parse_struct(_src, "kid_calving_in", ENUMS)
+
+
 class BondSoA(C.Structure):
     _fields_ = _parse_struct(_src, "kid_bond_soa", ENUMS)
 

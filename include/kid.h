@@ -11,6 +11,7 @@
  *   ice_bergs_framework_init, grid copy   FW:1021-1094     kid_create + kid_set_static_grid
  *   forcing ingest result (grd%uo ... )   IB:5236-5383     kid_set_forcing
  *   the forcing ingest block itself       IB:5236-5383     kid_ingest_forcing (+ kid_get_forcing for send_data)
+ *   calving block + accumulate_calving + calve_icebergs  IB:5203-5231, 5388, 5403   kid_calving
  *   accumulator zeroing                   IB:5125-5156     kid_zero_accumulators
  *   interp_gridded_fields_to_bergs        IB:5423, 5473    kid_interp_gridded_fields_to_bergs
  *   evolve_icebergs                       IB:5433          kid_evolve_icebergs
@@ -63,7 +64,7 @@ int kid_set_side_stream(kid_handle *h, void *side_stream, int enable);
 int kid_sync(kid_handle *h);
 const char *kid_last_error(const kid_handle *h);
 const char *kid_version(void);
-int64_t kid_sizeof(int which); /* 0 kid_params, 1 kid_grid_desc, 2 kid_berg_soa, 3 kid_bond_soa, 4 kid_forcing_in: ABI layout check */
+int64_t kid_sizeof(int which); /* 0 kid_params, 1 kid_grid_desc, 2 kid_berg_soa, 3 kid_bond_soa, 4 kid_forcing_in, 5 kid_calving_params, 6 kid_calving_in: ABI layout check */
 
 /* ---- grid and forcing (host pointers; KID_G_* / KID_F_* order) ---- */
 int kid_set_static_grid(kid_handle *h, const double *const fields[KID_NGRID_STATIC]);
@@ -99,6 +100,26 @@ int kid_ingest_forcing(kid_handle *h, const kid_forcing_in *in);
 /* grd%uo .. grd%hi as the handle holds them (KID_F_* order, data-domain planes, NULL entries skipped): what the
  * reference hands to send_data for id_uo, id_vo, ... (IB:5529-5548).  Needs kid_set_forcing or kid_ingest_forcing. */
 int kid_get_forcing(kid_handle *h, double *const fields[KID_NFORCING]);
+
+/* ---- calving source ----
+ * kid_calving is, in this order, the calving block of icebergs_run (IB:5203-5231: mask, running mean IB:5999-6038, kg/s),
+ * accumulate_calving (IB:6153-6222) and calve_icebergs (IB:6225-6402): the buckets grd%stored_ice(:,:,1:10) /
+ * grd%stored_heat live on the device, and bergs calved from overflowing buckets are appended to the resident SoA
+ * (ids from the per-cell counter, kid_set_iceberg_counter).  bergs%current_year / current_yearday come from kid_params.
+ * scalars[KID_NCALV_SCALARS]: what the call adds to the budget scalars of type icebergs (KID_CS_* order; may be NULL).
+ * Returns KID_ECAPACITY when the SoA cannot hold the new bergs.  Replaces IB:5203-5231, 5388, 5397, 5403. */
+int kid_set_calving_params(kid_handle *h, const kid_calving_params *cp);
+/* read_restart_calving: stored_ice (10 data-domain planes), stored_heat, the two running means; NULL keeps the handle's */
+int kid_set_calving_state(kid_handle *h, const double *stored_ice, const double *stored_heat, const double *rmean_calving,
+                          const double *rmean_calving_hflx);
+/* ... and for write_restart_calving / send_data (id_stored_ice, id_real_calving IB:5593-5600); NULL entries are skipped */
+int kid_get_calving_state(kid_handle *h, double *stored_ice, double *stored_heat, double *rmean_calving,
+                          double *rmean_calving_hflx, double *real_calving);
+int kid_calving(kid_handle *h, const kid_calving_in *in, double *scalars);
+/* grd%calving (kg/s, the unused remainder: id_unused IB:5396, returned to the coupler at IB:5656) and grd%calving_hflx
+ * after kid_calving; data-domain planes, NULL skipped.  The melt the step adds to grd%calving_hflx (IB:3129) is the
+ * accumulator KID_A_CALVING_HFLX. */
+int kid_get_calving(kid_handle *h, double *calving, double *calving_hflx);
 
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */

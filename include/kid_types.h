@@ -65,6 +65,45 @@ typedef struct kid_forcing_in {
   int32_t on_device, pad;                   /* pointers are device addresses (no staging copy) */
 } kid_forcing_in;
 
+/* ---- calving source: the calving block of icebergs_run IB:5203-5231, accumulate_calving IB:6153-6222 and
+ * calve_icebergs IB:6225-6402.  kid_calving_params holds the per-hemisphere namelist tables as
+ * ice_bergs_framework_init leaves them (FW:1534-1551; initial_mass_s/n are in kid_params). ---- */
+enum { KID_NCLASSES = 10 };     /* nclasses, FW:36 */
+typedef struct kid_calving_params {
+  double distribution_s[10], distribution_n[10];            /* FW:1535, 1544 */
+  double mass_scaling_s[10], mass_scaling_n[10];            /* FW:1536, 1545 */
+  double initial_thickness_s[10], initial_thickness_n[10];  /* FW:1537, 1546 */
+  double initial_width_s[10], initial_width_n[10];          /* FW:1540, 1549 */
+  double initial_length_s[10], initial_length_n[10];        /* FW:1541, 1550 */
+  double tau_calving;           /* bergs%tau_calving, IB:5215 (>0: running-mean calving, IB:5999-6038) */
+  int32_t restarted;            /* bergs%restarted: skips the first-call stored-heat initialisation, IB:6171 */
+  int32_t pad;
+} kid_calving_params;
+typedef struct kid_calving_in {
+  const double *calving;        /* (isc:iec, jsc:jec), kg/m2/s, IB:5078 */
+  const double *calving_hflx;   /* (isc:iec, jsc:jec), W/m2,    IB:5080 */
+  int32_t on_device, pad;       /* pointers are device addresses */
+} kid_calving_in;
+/* what one kid_calving call adds to the budget scalars of type icebergs (increments; the first two `stored` entries
+ * are the values the first call prints, zero afterwards) */
+enum {
+  KID_CS_NET_CALVING_RECEIVED = 0,        /* IB:5204 */
+  KID_CS_NET_INCOMING_CALVING,            /* IB:5223 */
+  KID_CS_NET_INCOMING_CALVING_HEAT,       /* IB:5231 */
+  KID_CS_STORED_START,                    /* IB:6176 */
+  KID_CS_STORED_HEAT_START,               /* IB:6186 */
+  KID_CS_NET_CALVING_USED,                /* IB:6212 */
+  KID_CS_NET_INCOMING_CALVING_HEAT_USED,  /* IB:6218 */
+  KID_CS_UNUSED_CALVING,                  /* IB:5397 (a value, not an increment) */
+  KID_CS_NET_CALVING_TO_BERGS,            /* IB:6399 */
+  KID_CS_NET_HEAT_TO_BERGS,               /* IB:6400 */
+  KID_CS_NBERGS_CALVED,                   /* IB:6383 */
+  KID_CS_ERROR_COUNT,                     /* FATALs of the block (berg not in its cell IB:6281) + SoA overflow */
+  KID_CS_NBERGS_CALVED_BY_CLASS_S,        /* 10 entries, IB:6385 */
+  KID_CS_NBERGS_CALVED_BY_CLASS_N = KID_CS_NBERGS_CALVED_BY_CLASS_S + 10,   /* 10 entries, IB:6387 */
+  KID_NCALV_SCALARS = KID_CS_NBERGS_CALVED_BY_CLASS_N + 10
+};
+
 /* ---- per-berg fp64 fields (type iceberg, FW:294-343) ---- */
 enum {
   KID_B_LON = 0, KID_B_LAT, KID_B_UVEL, KID_B_VVEL,

@@ -87,6 +87,16 @@ void ko_find_orientations(const ko_grid *g, const kid_params *p, kid_berg_soa *b
 void ko_evolve_icebergs_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars);
 void ko_run_step_interactive(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, int first_visit,
                              double *acc, double *out, double *scalars);
+/* calving source (oracle/kid_oracle_calving.c), IB:5203-5231 + accumulate_calving IB:6153 + calve_icebergs IB:6225.
+ * All planes cover the data domain; stored_ice / real_calving are KID_NCLASSES consecutive planes. */
+typedef struct ko_calving_state {
+  double *calving, *calving_hflx;                 /* grd%calving (kg/s after the call: the unused remainder), grd%calving_hflx */
+  double *stored_ice, *stored_heat, *real_calving;
+  double *rmean_calving, *rmean_calving_hflx;
+  int32_t first_call, rmean_calving_initialized, rmean_calving_hflx_initialized, pad;
+} ko_calving_state;
+int ko_calving(const ko_grid *g, const kid_params *p, const kid_calving_params *cp, const double *calving_in,
+               const double *calving_hflx_in, ko_calving_state *s, kid_berg_soa *b, int64_t capacity, double *scalars);
 /* forcing ingest (oracle/kid_oracle_ingest.c), IB:5236-5383; returns non-zero on inconsistent extents / staggers */
 int ko_ingest_forcing(const ko_grid *g, const kid_forcing_in *in, double *const out[KID_NFORCING]);
 void ko_default_params(kid_params *p);

@@ -14,6 +14,12 @@ sys.path.insert(0, os.path.join(_HERE, ".."))
 from icebergs_amd import types as T  # noqa: E402  (interface types only)
 
 
+class KoCalvingState(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("calving", "calving_hflx", "stored_ice", "stored_heat", "real_calving",
+                                                     "rmean_calving", "rmean_calving_hflx")] + \
+               [(n, C.c_int32) for n in ("first_call", "rmean_calving_initialized", "rmean_calving_hflx_initialized", "pad")]
+
+
 class KoGrid(C.Structure):
     _fields_ = [("d", T.GridDesc),
                 ("stat", C.POINTER(C.c_double) * T.ENUMS["KID_NGRID_STATIC"]),
@@ -62,6 +68,9 @@ def load():
                                       C.POINTER(d), C.POINTER(d)]
     lib.ko_default_params.restype = None
     lib.ko_default_params.argtypes = [C.POINTER(T.Params)]
+    lib.ko_calving.restype = C.c_int
+    lib.ko_calving.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.CalvingParams), C.POINTER(d), C.POINTER(d),
+                               C.POINTER(KoCalvingState), C.POINTER(T.BergSoA), C.c_int64, C.POINTER(d)]
     lib.ko_ingest_forcing.restype = C.c_int
     lib.ko_ingest_forcing.argtypes = [C.POINTER(KoGrid), C.POINTER(T.ForcingIn), C.POINTER(C.POINTER(d))]
     for name in ("ko_interp_gridded_fields_to_bergs",):
@@ -145,6 +154,31 @@ class Oracle:
         arr = (C.POINTER(C.c_double) * T.ENUMS["KID_NFORCING"])(*[_dp(out[name]) for name in T.FORCING_NAMES])
         rc = self.lib.ko_ingest_forcing(C.byref(self.kg), C.byref(fin), arr)
         return out if rc == 0 else None
+
+    def new_calving_state(self):
+        """grd%calving .. grd%rmean_calving_hflx as ice_bergs_framework_init leaves them (zeros), first_call = T"""
+        nk = T.ENUMS["KID_NCLASSES"]
+        st = {"calving": np.zeros((self.nj, self.ni)), "calving_hflx": np.zeros((self.nj, self.ni)),
+              "stored_ice": np.zeros((nk, self.nj, self.ni)), "stored_heat": np.zeros((self.nj, self.ni)),
+              "real_calving": np.zeros((nk, self.nj, self.ni)), "rmean_calving": np.zeros((self.nj, self.ni)),
+              "rmean_calving_hflx": np.zeros((self.nj, self.ni)), "flags": [1, 0, 0]}
+        return st
+
+    def calving(self, cp, calving, calving_hflx, state, bergs, capacity):
+        """ko_calving (IB:5203-5231, 6153-6402): updates `state` and appends to `bergs` (arrays sized `capacity`, bergs["_n"] rows live)"""
+        ks = KoCalvingState()
+        for n in ("calving", "calving_hflx", "stored_ice", "stored_heat", "real_calving", "rmean_calving", "rmean_calving_hflx"):
+            assert state[n].dtype == np.float64 and state[n].flags.c_contiguous
+            setattr(ks, n, _dp(state[n]))
+        ks.first_call, ks.rmean_calving_initialized, ks.rmean_calving_hflx_initialized = state["flags"]
+        a = np.ascontiguousarray(calving, dtype=np.float64)
+        b = np.ascontiguousarray(calving_hflx, dtype=np.float64)
+        soa = self.soa(bergs)
+        scal = np.zeros(T.ENUMS["KID_NCALV_SCALARS"])
+        rc = self.lib.ko_calving(C.byref(self.kg), C.byref(self.params), C.byref(cp), _dp(a), _dp(b), C.byref(ks), C.byref(soa), int(capacity), _dp(scal))
+        state["flags"] = [ks.first_call, ks.rmean_calving_initialized, ks.rmean_calving_hflx_initialized]
+        bergs["_n"] = int(soa.n)
+        return rc, scal
 
     @staticmethod
     def soa(bergs):

@@ -29,6 +29,7 @@ def test_struct_layouts_match():
     assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)
     assert lib.kid_sizeof(3) == C.sizeof(T.BondSoA)
     assert lib.kid_sizeof(4) == C.sizeof(T.ForcingIn)
+    assert lib.kid_sizeof(5) == C.sizeof(T.CalvingParams) and lib.kid_sizeof(6) == C.sizeof(T.CalvingIn)
     assert lib.kid_version().startswith(b"kid_hip")
 
 
@@ -63,5 +64,5 @@ def test_structs_have_no_implicit_padding():
     """Fortran stream I/O and bind(C) derived types move components one by one: every pad must be spelled out"""
     import ctypes
     from icebergs_amd import types as T
-    for cls in (T.Params, T.GridDesc, T.BergSoA, T.BondSoA, T.ForcingIn):
+    for cls in (T.Params, T.GridDesc, T.BergSoA, T.BondSoA, T.ForcingIn, T.CalvingParams, T.CalvingIn):
         assert ctypes.sizeof(cls) == sum(ctypes.sizeof(t) for _, t in cls._fields_), cls.__name__

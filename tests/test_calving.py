@@ -1,0 +1,227 @@
+"""Calving source (icebergs.F90:5203-5231, accumulate_calving IB:6153, calve_icebergs IB:6225):
+oracle self-checks on the CPU, HIP-vs-oracle parity on the GPU.
+
+No recorded vector exists for this block (PARITY UNPINNED, see oracle/kid_oracle_calving.c); the CPU tests pin the
+restatement against a hand-computed single-cell case and the mass / heat budgets the block must close."""
+import numpy as np
+import pytest
+
+from icebergs_amd import synthetic as S
+from icebergs_amd import types as T
+from oracle import oracle_lib as O
+
+E = T.ENUMS
+
+
+def _setup(n=300, ni=60, nj=200, seed=4, old_order=True, tau=0.0, restarted=False, footloose=False):
+    """a lat-lon grid over both hemispheres (-80..80) with config-2 forcing and a few resident bergs"""
+    grid, p, b = S.config_c2(n=n, seed=seed)
+    if ni != 360:
+        grid = S.c2_forcing(S.latlon_grid(ni=ni, nj=nj, dlon=360.0 / ni))
+        b = S.place_bergs(grid, n, seed, (3, ni - 3), (3, nj - 3))
+    p.old_interp_flds_order = 1 if old_order else 0
+    p.current_year, p.current_yearday = 7, 123.25
+    cp = S.calving_params(p, tau_calving=tau, restarted=restarted)
+    return grid, p, cp, b
+
+
+def _with_room(b, capacity):
+    out = S.empty_bergs(capacity)
+    n = len(b["lon"])
+    for k, v in b.items():
+        out[k][:n] = v
+    out["alive"][n:] = 0
+    out["_n"] = n
+    return out
+
+
+def test_oracle_single_cell_by_hand():
+    grid, p, cp, b = _setup(n=1)
+    d = grid["desc"]
+    orc = O.Oracle(grid, p)
+    st = orc.new_calving_state()
+    nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+    i, j = 17, 40                                   # southern hemisphere cell (lat = -80 + 0.8 j < 0)
+    c = (j - d.jsd, i - d.isd)
+    area = grid["static"]["area"][c]
+    bucket = p.initial_mass_s[0] * cp.mass_scaling_s[0]          # class 1: 8.8e7 kg x 2000
+    calv = np.zeros((njc, nic))
+    hflx = np.zeros((njc, nic))
+    rate = 2.5 * bucket / (cp.distribution_s[0] * p.dt * area)   # fills class 1 with 2.5 buckets in one step
+    calv[j - d.jsc, i - d.isc] = rate
+    hflx[j - d.jsc, i - d.isc] = -3.0
+    bergs = _with_room(b, 64)
+    rc, scal = orc.calving(cp, calv, hflx, st, bergs, 64)
+    total = 2.5 * bucket / cp.distribution_s[0]                     # kg delivered to the cell this step
+    per_class = [int(np.floor(total * cp.distribution_s[k] / (p.initial_mass_s[k] * cp.mass_scaling_s[k]) * (1 + 1e-12))) for k in range(10)]
+    assert per_class[0] == 2 and sum(per_class) > 2
+    assert rc == 0 and bergs["_n"] == 1 + sum(per_class) and scal[E["KID_CS_NBERGS_CALVED"]] == sum(per_class)
+    assert list(scal[E["KID_CS_NBERGS_CALVED_BY_CLASS_S"]:E["KID_CS_NBERGS_CALVED_BY_CLASS_N"]]) == per_class
+    assert scal[E["KID_CS_NBERGS_CALVED_BY_CLASS_N"]:].sum() == 0
+    kg_s = rate * area
+    assert np.isclose(scal[E["KID_CS_NET_CALVING_RECEIVED"]], kg_s * p.dt, rtol=1e-14)
+    assert np.isclose(scal[E["KID_CS_NET_CALVING_USED"]], kg_s * p.dt * sum(cp.distribution_s), rtol=1e-13)
+    assert np.isclose(st["stored_ice"][0][c], 0.5 * bucket, rtol=1e-9)
+    assert np.isclose(st["real_calving"][0][c], 2 * bucket / p.dt, rtol=1e-14)
+    assert np.isclose(scal[E["KID_CS_NET_CALVING_TO_BERGS"]], sum(per_class[k] * p.initial_mass_s[k] * cp.mass_scaling_s[k] for k in range(10)), rtol=1e-14)
+    for q, ddt in ((1, 0.0), (2, -p.dt * 2.0 / 17.0)):
+        assert bergs["mass"][q] == p.initial_mass_s[0] and bergs["mass_scaling"][q] == cp.mass_scaling_s[0]
+        assert bergs["thickness"][q] == cp.initial_thickness_s[0] and bergs["length"][q] == 1.5 * bergs["width"][q]
+        assert bergs["ine"][q] == i and bergs["jne"][q] == j and bergs["start_year"][q] == 7
+        assert bergs["start_day"][q] == 123.25 + ddt / 86400.0
+        assert abs(bergs["xi"][q] - 0.5) < 1e-9 and abs(bergs["yj"][q] - 0.5) < 1e-3   # the mean of the four corners
+        assert bergs["id"][q] == (q << 32) + i + nic * (j - 1)                            # generate_id, counter 1 and 2
+    # heat: first call -> stored_heat starts from zero ice; then dt*hflx*area*(1-remaining) comes in, two bergs take their share
+    used = p.dt * (-3.0) * area * sum(cp.distribution_s)
+    assert np.isclose(scal[E["KID_CS_NET_INCOMING_CALVING_HEAT_USED"]], used, rtol=1e-13)
+    hd1 = used / (kg_s * p.dt * cp.distribution_s[0])   # IB:6329 divides the cell's heat by the CLASS's ice
+    assert np.isclose(bergs["heat_density"][1], hd1, rtol=1e-13)
+    assert np.isclose(st["stored_heat"][c] + scal[E["KID_CS_NET_HEAT_TO_BERGS"]], used, rtol=1e-12)
+    rd = 1.0
+    for k in range(10):
+        rd = rd - cp.distribution_s[k]
+    assert np.isclose(st["calving"][c], kg_s * rd, rtol=1e-14) and np.isclose(scal[E["KID_CS_UNUSED_CALVING"]], kg_s * rd, rtol=1e-14)   # 1 %
+
+
+def test_oracle_budgets_close_over_steps():
+    grid, p, cp, b = _setup(n=50, tau=3.0e6)
+    d = grid["desc"]
+    orc = O.Oracle(grid, p)
+    st = orc.new_calving_state()
+    cap = 12000
+    bergs = _with_room(b, cap)
+    sl = (slice(d.jsc - d.jsd, d.jec - d.jsd + 1), slice(d.isc - d.isd, d.iec - d.isd + 1))
+    tot = np.zeros(E["KID_NCALV_SCALARS"])
+    stored0 = st["stored_ice"][:, sl[0], sl[1]].sum()
+    for step in range(5):
+        calv, hflx = S.coupler_calving(grid, seed=step % 2, frac=0.04)
+        rc, scal = orc.calving(cp, calv, hflx, st, bergs, cap)
+        assert rc == 0
+        tot += scal
+    ncal = int(tot[E["KID_CS_NBERGS_CALVED"]])
+    assert ncal > 100 and bergs["_n"] == 50 + ncal
+    assert ncal == tot[E["KID_CS_NBERGS_CALVED_BY_CLASS_S"]:E["KID_CS_NBERGS_CALVED_BY_CLASS_S"] + 20].sum()
+    assert tot[E["KID_CS_NBERGS_CALVED_BY_CLASS_S"]:E["KID_CS_NBERGS_CALVED_BY_CLASS_N"]].sum() > 0 and tot[E["KID_CS_NBERGS_CALVED_BY_CLASS_N"]:].sum() > 0
+    stored1 = st["stored_ice"][:, sl[0], sl[1]].sum()
+    assert np.isclose(stored1 - stored0, tot[E["KID_CS_NET_CALVING_USED"]] - tot[E["KID_CS_NET_CALVING_TO_BERGS"]], rtol=1e-10)
+    new = slice(50, bergs["_n"])
+    assert np.isclose((bergs["mass"][new] * bergs["mass_scaling"][new]).sum(), tot[E["KID_CS_NET_CALVING_TO_BERGS"]], rtol=1e-12)
+    assert np.isclose((bergs["mass"][new] * bergs["mass_scaling"][new] * bergs["heat_density"][new]).sum(), tot[E["KID_CS_NET_HEAT_TO_BERGS"]], rtol=1e-10)
+    heat1 = st["stored_heat"][sl].sum()
+    assert np.isclose(heat1, tot[E["KID_CS_STORED_HEAT_START"]] + tot[E["KID_CS_NET_INCOMING_CALVING_HEAT_USED"]] - tot[E["KID_CS_NET_HEAT_TO_BERGS"]], rtol=1e-9)
+    assert len(np.unique(bergs["id"][:bergs["_n"]])) == bergs["_n"]
+    assert st["flags"] == [0, 1, 1]
+
+
+def _compare_state(ref, got, label):
+    for name in ("calving", "calving_hflx", "stored_ice", "stored_heat", "real_calving", "rmean_calving", "rmean_calving_hflx"):
+        assert np.array_equal(got[name], ref[name]), (label, name, float(np.abs(got[name] - ref[name]).max()))
+
+
+def _compare_new_bergs(rb, gb, n0, label):
+    nr = rb["_n"]
+    assert len(gb["lon"]) == nr, (label, len(gb["lon"]), nr)
+    orr = np.argsort(rb["id"][:nr], kind="stable")
+    org = np.argsort(gb["id"], kind="stable")
+    assert np.array_equal(rb["id"][:nr][orr], gb["id"][org]), label
+    for f in T.BERG_I32_NAMES:
+        assert np.array_equal(rb[f][:nr][orr], gb[f][org]), (label, f)
+    for f in T.BERG_F64_NAMES:
+        r, g = rb[f][:nr][orr], gb[f][org]
+        if f in ("xi", "yj", "uo", "vo", "ui", "vi", "ua", "va", "ssh_x", "ssh_y", "sst", "sss", "cn", "hi", "od"):
+            assert np.allclose(g, r, rtol=1e-12, atol=1e-13), (label, f, float(np.abs(g - r).max()))
+        else:
+            assert np.array_equal(g, r), (label, f, np.nonzero(g != r)[0][:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "running_mean", "restarted", "stored_env"])
+def test_calving_parity(variant):
+    """planes bit-exact (pointwise arithmetic in the reference's order), new bergs bit-exact but for the in-cell position
+    and the interpolated environment (1e-12), budget sums to 1e-12 (they are reductions)"""
+    from icebergs_amd.framework import Icebergs
+    grid, p, cp, b = _setup(n=200, tau=3.0e6 if variant == "running_mean" else 0.0, restarted=variant == "restarted", old_order=variant != "stored_env")
+    orc = O.Oracle(grid, p)
+    st = orc.new_calving_state()
+    cap = 12000
+    ib = Icebergs(grid, p, capacity=cap)
+    ib.set_forcing(grid["forcing"])
+    ib.set_calving_params(cp)
+    if variant == "restarted":   # buckets from a restart file: part full, heat already there, running means absent
+        rng = np.random.default_rng(8)
+        st["stored_ice"][:] = rng.uniform(0, 0.4, st["stored_ice"].shape) * (S.INITIAL_MASS * np.array([2000, 200, 50, 20, 10, 5, 2, 1, 1, 1]))[:, None, None]
+        st["stored_heat"][:] = -rng.uniform(1e3, 3e4, st["stored_heat"].shape) * st["stored_ice"].sum(axis=0)
+        ib.set_calving_state(stored_ice=st["stored_ice"], stored_heat=st["stored_heat"])
+    bergs = _with_room(b, cap)
+    ib.upload_bergs(b)
+    for step in range(4):
+        calv, hflx = S.coupler_calving(grid, seed=step % 2, frac=0.04)
+        rc, rscal = orc.calving(cp, calv, hflx, st, bergs, cap)
+        assert rc == 0
+        gscal = ib.calving(calv, hflx)
+        label = "%s step %d" % (variant, step)
+        _compare_state(st, ib.get_calving_state(), label)
+        assert np.allclose(gscal, rscal, rtol=1e-12, atol=0), (label, gscal, rscal)
+        _compare_new_bergs(bergs, ib.download_bergs(), 200, label)
+        assert np.array_equal(ib.get_iceberg_counter(), orc.iceberg_counter), label
+    assert bergs["_n"] > 400
+    ib.close()
+
+
+@pytest.mark.gpu
+def test_calving_then_step_matches_oracle():
+    """the calved bergs take part in the following steps exactly like uploaded ones (re-binning included)"""
+    import parity as P
+    from icebergs_amd.framework import Icebergs
+    grid, p, cp, b = _setup(n=500)
+    orc = O.Oracle(grid, p)
+    st = orc.new_calving_state()
+    cap = 16000
+    ib = Icebergs(grid, p, capacity=cap)
+    ib.set_forcing(grid["forcing"])
+    ib.set_calving_params(cp)
+    ib.set_resort_interval(2)
+    bergs = _with_room(b, cap)
+    ib.upload_bergs(b)
+    for step in range(6):
+        calv, hflx = S.coupler_calving(grid, seed=step % 3, frac=0.03)
+        orc.calving(cp, calv, hflx, st, bergs, cap)
+        orc.run_step(bergs, 1)
+        ib.calving(calv, hflx)
+        ib.run(1)
+    acc, out, scal = ib.fetch()
+    got = (ib.download_bergs(), acc.copy(), out.copy(), scal.copy())
+    ref = (bergs, orc.acc.copy(), orc.out.copy(), orc.scalars.copy())
+    assert bergs["_n"] > 1000
+    P.compare(ref, got, "calving+step", params=p)
+    ib.close()
+
+
+@pytest.mark.gpu
+def test_calving_capacity_and_device_inputs():
+    import torch
+    from icebergs_amd import lib as L
+    from icebergs_amd.framework import Icebergs
+    grid, p, cp, b = _setup(n=100)
+    calv, hflx = S.coupler_calving(grid, seed=1, frac=0.05, buckets=4.0)
+    orc = O.Oracle(grid, p)
+    st = orc.new_calving_state()
+    bergs = _with_room(b, 20000)
+    rc, _ = orc.calving(cp, calv, hflx, st, bergs, 20000)
+    assert rc == 0 and bergs["_n"] > 300
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (calv, hflx)]
+    ib = Icebergs(grid, p, capacity=20000)
+    ib.set_forcing(grid["forcing"])
+    ib.set_calving_params(cp)
+    ib.upload_bergs(b)
+    ib.calving(dev[0].data_ptr(), dev[1].data_ptr(), on_device=True)
+    assert ib.num_bergs()[0] == bergs["_n"]
+    _compare_state(st, ib.get_calving_state(), "device inputs")
+    ib.close()
+    small = Icebergs(grid, p, capacity=110)
+    small.set_forcing(grid["forcing"])
+    small.set_calving_params(cp)
+    small.upload_bergs(b)
+    with pytest.raises(L.KidError, match="rc=-4"):
+        small.calving(calv, hflx)
+    small.close()

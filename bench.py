@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce and the gather on the critical path")
     ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
+    ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)
     args = ap.parse_args()
@@ -96,10 +97,12 @@ def main():
     from icebergs_amd.distributed import ShardedStepper, PipelinedStepper, accumulator_views
     _, count = ib.accum_device_ptr()
     multi = world > 1 or args.force_collective
-    pipelined = (multi and not args.no_pipeline) or args.split_general
+    slow_lane = not args.no_slow_lane and not args.split_general and not args.no_pipeline
+    pipelined = (multi and not args.no_pipeline) or args.split_general or slow_lane
     if pipelined:
-        # N>1: the all-reduce and the gather of step k run on a second stream under the per-berg kernels of step k+1
-        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective, split_general=args.split_general)
+        # the all-reduce (N>1) and the gather of step k run on a second stream under the per-berg kernels of step k+1;
+        # slow lane: so do the general-build launches (bergs that crossed a cell edge or bounced)
+        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective, split_general=args.split_general, slow_lane=slow_lane)
         nreduced = stepper.views[0][0].numel()
     else:
         acc_t = torch.zeros(count, dtype=torch.float64, device=dev)

@@ -106,7 +106,10 @@ __global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec
 #ifndef KID_GENERAL_WAVES_PER_EU
 #define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
 #endif
-struct Redo { int *list; int *count; long long k0, klen; };   // k0, klen: the rows the hot build covers in this launch
+struct Redo { int *list; int *count; long long k0, klen; int *lane; int step; };   // k0, klen: the rows the hot build covers in this launch
+// lane/step ("slow lane" schedule, launch_berg_lanes): lane[k] >= step means berg k is owned by general-build launches that
+// may still be running on the side stream; the hot build of this step leaves it alone.  A berg the hot build hands over
+// at step s gets lane = s + 1: the general build does its steps s and s + 1, the hot build has it back at s + 2.
 #ifdef KID_EXP_NUM_VGPR
 #define KID_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(KID_EXP_NUM_VGPR)))
 #else
@@ -134,6 +137,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
   bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
+  if (FAST && redo.lane) { if (was_alive && redo.lane[kk] >= redo.step) was_alive = false; }
   if (__ballot(was_alive) == 0ull) continue;  // wave-uniform; every other lane stays to the end (wave-level sums below)
   double *scal = acc + (size_t)KID_NACC * ncell;
 
@@ -152,7 +156,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     // general build one by one (handing over the whole wave made 15 % of the population take the slow path by the end
     // of a 16-step interval).
     if (myrun >= KID_MAXRUN) {
-      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; }
+      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
       was_alive = false;
     }
     if (__ballot(was_alive) == 0ull) continue;
@@ -207,6 +211,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
         const int slot = atomicAdd(redo.count, 1);
         redo.list[slot] = (int)kk;
+        if (redo.lane) redo.lane[kk] = redo.step + 1;
         skipped = true; tickets = 0u; err = 0;
       } else {
         // a berg whose cell leaves the computational domain is packed-and-deleted by send_bergs_to_other_pes on a
@@ -449,6 +454,10 @@ struct kid_handle {
   bool env_ever_stored = false;            // some launch since the last upload wrote berg%uo..od
   double *d_orient = nullptr;              // bond-derived hexagon orientation per berg (mts / interacting bergs)
   hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
+  // "slow lane" schedule (kid_set_side_stream mode 2, launch_berg_lanes)
+  int side_mode = 0; int *d_lane = nullptr; int lane_step = 1; bool lanes_active = false, carry_valid = false, evC_live = false;
+  hipEvent_t evC = nullptr, evP = nullptr;
+  VelRec *d_vel2 = nullptr; TrcRec *d_trc2 = nullptr; DevGrid *d_grid2 = nullptr; int forc_parity = 0;  // forcing records of the odd steps
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   int *d_fl_cursor = nullptr;
   unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
@@ -489,7 +498,7 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.isd = h->gd.isd; g.ied = h->gd.ied; g.jsd = h->gd.jsd; g.jed = h->gd.jed;
   g.isc = h->gd.isc; g.iec = h->gd.iec; g.jsc = h->gd.jsc; g.jec = h->gd.jec;
   g.ni = h->ni; g.nj = h->nj; g.latlon = h->gd.grid_is_latlon; g.regular = h->gd.grid_is_regular; g.Lx = h->gd.Lx;
-  g.vel = h->d_vel; g.trc = h->d_trc; g.geo = h->d_geo;
+  g.vel = h->forc_parity ? h->d_vel2 : h->d_vel; g.trc = h->forc_parity ? h->d_trc2 : h->d_trc; g.geo = h->d_geo;
   g.dx = h->d_static[KID_G_DX]; g.dy = h->d_static[KID_G_DY]; g.ocean_depth = h->d_static[KID_G_OCEAN_DEPTH];
   g.ssh = h->d_forcing[KID_F_SSH];
   g.sin_lat_ref = sin((h->params.pi / 180.) * h->params.lat_ref);
@@ -593,6 +602,12 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_bp, sizeof(BergPtrs)));
   KID_HIP(h, hipMalloc(&h->d_params, sizeof(kid_params)));
   KID_HIP(h, hipMalloc(&h->d_grid, sizeof(DevGrid)));
+  KID_HIP(h, hipMalloc(&h->d_grid2, sizeof(DevGrid)));
+  KID_HIP(h, hipMalloc(&h->d_vel2, h->ncell * sizeof(VelRec)));
+  KID_HIP(h, hipMalloc(&h->d_trc2, h->ncell * sizeof(TrcRec)));
+  KID_HIP(h, hipMalloc(&h->d_lane, (size_t)capacity * sizeof(int)));
+  KID_HIP(h, hipMemset(h->d_lane, 0, (size_t)capacity * sizeof(int)));
+  KID_HIP(h, hipEventCreateWithFlags(&h->evC, hipEventDisableTiming)); KID_HIP(h, hipEventCreateWithFlags(&h->evP, hipEventDisableTiming));
   KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
   KID_HIP(h, hipMalloc(&h->d_iceberg_counter, h->ncell * sizeof(int32_t)));
   KID_HIP(h, hipMemset(h->d_iceberg_counter, 0, h->ncell * sizeof(int32_t)));
@@ -645,6 +660,12 @@ int kid_destroy(kid_handle *h) {
   if (h->d_bp) (void)hipFree(h->d_bp);
   if (h->d_params) (void)hipFree(h->d_params);
   if (h->d_grid) (void)hipFree(h->d_grid);
+  if (h->d_grid2) (void)hipFree(h->d_grid2);
+  if (h->d_vel2) (void)hipFree(h->d_vel2);
+  if (h->d_trc2) (void)hipFree(h->d_trc2);
+  if (h->d_lane) (void)hipFree(h->d_lane);
+  if (h->evC) (void)hipEventDestroy(h->evC);
+  if (h->evP) (void)hipEventDestroy(h->evP);
   for (int q = 0; q < 2; ++q) { if (h->d_key[q]) (void)hipFree(h->d_key[q]); if (h->d_idx[q]) (void)hipFree(h->d_idx[q]); }
   if (h->d_sort_tmp) (void)hipFree(h->d_sort_tmp);
   if (h->d_perm_spare) (void)hipFree(h->d_perm_spare);
@@ -682,6 +703,17 @@ static int refresh_tables(kid_handle *h);
 static int join_side(kid_handle *h) {
   for (int q = 0; q < 2; ++q)
     if (h->evG_live[q]) { KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[q], 0)); }
+  if (h->evC_live) { KID_HIP(h, hipStreamWaitEvent(h->stream, h->evC, 0)); }
+  return KID_OK;
+}
+// Leave the slow-lane schedule: both lanes are complete through the last step once the side stream is joined, so every
+// berg can go back to the hot build and nothing is carried over.  Needed before anything that moves rows (the lists
+// hold row numbers) or that launches outside launch_berg_lanes.
+static int lanes_drain(kid_handle *h) {
+  const int rc = join_side(h);
+  if (rc || !h->lanes_active) return rc;
+  KID_HIP(h, hipMemsetAsync(h->d_lane, 0, (size_t)h->capacity * sizeof(int), h->stream));
+  h->lanes_active = false; h->carry_valid = false; h->lane_step = 1;
   return KID_OK;
 }
 int kid_set_side_stream(kid_handle *h, void *s, int enable) {
@@ -690,9 +722,12 @@ int kid_set_side_stream(kid_handle *h, void *s, int enable) {
   int rc = join_side(h);
   if (rc) return rc;
   KID_HIP(h, hipStreamSynchronize(h->stream));
-  h->evG_live[0] = h->evG_live[1] = false;
+  { const int rc_d = lanes_drain(h); if (rc_d) return rc_d; }
+  KID_HIP(h, hipStreamSynchronize(h->stream));
+  h->evG_live[0] = h->evG_live[1] = false; h->evC_live = false;
   h->side_stream = (hipStream_t)s;
-  h->pipelined = enable != 0;
+  h->pipelined = enable == 1;
+  h->side_mode = (s && enable == 2) ? 2 : 0;
   return KID_OK;
 }
 int kid_set_stream(kid_handle *h, void *s) {
@@ -725,7 +760,9 @@ static int pack_forcing(kid_handle *h, const double *const src[KID_NFORCING], co
   for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
   for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = src[k] ? src[k] : h->d_forcing[k];
   const int nb = (int)((h->ncell + 255) / 256);
-  hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_vel, h->d_trc, h->ni, h->nj, ex);
+  // a side stream is in use: general-build launches of the previous step may still read its records -> alternate two sets
+  if (h->side_mode == 2 || h->pipelined) h->forc_parity ^= 1;
+  hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->forc_parity ? h->d_vel2 : h->d_vel, h->forc_parity ? h->d_trc2 : h->d_trc, h->ni, h->nj, ex);
   KID_HIP(h, hipGetLastError());
   return KID_OK;
 }
@@ -785,6 +822,10 @@ int kid_step_prepare(kid_handle *h, const double *const fields[KID_NFORCING]) {
   const double *none[KID_NFORCING] = {};
   const double *const *src = fields ? fields : none;
   h->redo_parity ^= 1;
+  if (h->side_mode == 2) {  // slow-lane schedule: the counter this prepass zeroes is the one the last carry-over launch read
+    h->redo_parity = h->lane_step & 1;
+    if (h->evC_live) { KID_HIP(h, hipStreamWaitEvent(h->stream, h->evC, 0)); }
+  }
   PrepExtras ex;
   ex.ssh_copy = (src[KID_F_SSH] && src[KID_F_SSH] != h->d_forcing[KID_F_SSH]) ? h->d_forcing[KID_F_SSH] : nullptr;
   ex.acc = h->d_acc; ex.zero_planes = nacc_active(h);
@@ -802,7 +843,7 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   if (!h || !host || host->n < 0) return KID_EINVAL;
   if (host->n > h->capacity) { h->err = "more bergs than capacity"; return KID_ECAPACITY; }
   KID_HIP(h, hipSetDevice(h->device));
-  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
+  { const int rc_j = lanes_drain(h); if (rc_j) return rc_j; }
   const size_t n = (size_t)host->n;
   bool any_static = false, any_fl = false;
   for (int f = 0; f < KID_NB_F64; ++f) {
@@ -887,7 +928,7 @@ int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
 int kid_compact_bergs(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
-  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
+  { const int rc_j = lanes_drain(h); if (rc_j) return rc_j; }
   if (h->n == 0) return KID_OK;
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
@@ -960,7 +1001,7 @@ static bool field_never_written(const kid_handle *h, int f) {
 int kid_move_berg_between_cells(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
-  { const int rc_j = join_side(h); if (rc_j) return rc_j; }
+  { const int rc_j = lanes_drain(h); if (rc_j) return rc_j; }
   h->steps_since_sort = 0;
   if (h->n == 0) return KID_OK;
   if (h->have_bonds) { h->err = "bergs with bonds keep their rows: no re-binning while bond tables exist"; return KID_EUNSUPPORTED; }
@@ -1037,7 +1078,9 @@ static int launch_berg(kid_handle *h) {
   if (h->n == 0) return KID_OK;
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+{ int rc_t = lanes_drain(h); if (rc_t) return rc_t; }
 { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
+  const DevGrid *gtab = h->forc_parity ? h->d_grid2 : h->d_grid;
   h->tail_valid = false;
   if (h->flags.store_env || !old) h->env_ever_stored = true;
   // pass 1: every berg through the specialised build; pass 2: the general build over the bergs pass 1 queued
@@ -1052,7 +1095,7 @@ static int launch_berg(kid_handle *h) {
     const long long k0 = (nparts == 1) ? 0 : (part == 0 ? 0 : half);
     const long long klen = (nparts == 1) ? h->n : (part == 0 ? half : h->n - half);
     const unsigned nbp = (unsigned)((klen + 255) / 256);
-    const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen};
+    const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen, nullptr, 0};
     hipStream_t gs = (nparts == 2) ? h->side_stream : h->stream;
     if (h->evG_live[part]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[part], 0));
     if (nparts == 1 && h->evG_live[1]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[1], 0));
@@ -1063,10 +1106,10 @@ static int launch_berg(kid_handle *h) {
     }
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, (const DevGrid *)h->d_grid, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \
     if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(4u * nbp < 2048u ? 4u * nbp : 2048u), dim3(64), 0, gs, (const DevGrid *)h->d_grid, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(4u * nbp < 2048u ? 4u * nbp : 2048u), dim3(64), 0, gs, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
     if (nparts == 2) { (void)hipEventRecord(h->evG[part], gs); h->evG_live[part] = true; } else h->evG_live[part] = false;      \
   } while (0)
     if (rk && old) KID_LAUNCH(true, true);
@@ -1076,6 +1119,69 @@ static int launch_berg(kid_handle *h) {
 #undef KID_LAUNCH
   }
   if (nparts == 1) h->evG_live[1] = false;
+  h->redo_prezeroed = false;
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
+
+// The "slow lane" schedule of the fused step (kid_set_side_stream mode 2).  The general build is a single-wave latency
+// (~65 us for the few per cent of bergs that cross a cell edge or bounce) during which the chip idles.  Here it never
+// sits between two hot builds: a berg the hot build of step s hands over is stepped by general-build launches on the
+// side stream for steps s and s + 1 and returns to the hot build at s + 2:
+//   main: prepass(s) | hot(s) ..................................... | prepass(s+1) | hot(s+1) ...
+//   side:            | carry(s): step s of the bergs handed over at s-1 | new(s): step s of those handed over at s | gather(s)
+// carry(s) starts with hot(s) and is long finished when hot(s+1) starts (event evC, normally already signalled);
+// new(s) runs under hot(s+1), which skips its bergs (lane[k] >= s+1).  Per-step sums go to the accumulator block bound
+// at launch; the caller alternates two blocks and launches the gather on the side stream (PipelinedStepper).
+static bool lanes_eligible(const kid_handle *h) {
+  const kid_params &p = h->params;
+  return h->side_mode == 2 && h->side_stream && p.old_interp_flds_order && !p.static_icebergs && !p.mts && !p.interactive_icebergs_on &&
+         !p.footloose && !(p.grounding_fraction > 0.) && h->n >= 4096;
+}
+static int launch_berg_lanes(kid_handle *h) {
+  constexpr unsigned PH = PH_EVOLVE | PH_THERMO | PH_SPREAD;
+  if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
+  { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
+  const bool rk = h->params.Runge_not_Verlet != 0;
+  const DevGrid *gtab = h->forc_parity ? h->d_grid2 : h->d_grid;
+  hipStream_t M = h->stream, S = h->side_stream;
+  const int s = h->lane_step, par = s & 1;
+  h->tail_valid = false;
+  if (h->flags.store_env) h->env_ever_stored = true;
+  h->lanes_active = true;
+  for (int q = 0; q < 2; ++q) if (h->evG_live[q] && h->pipelined) { KID_HIP(h, hipStreamWaitEvent(M, h->evG[q], 0)); h->evG_live[q] = false; }
+  if (!h->redo_prezeroed) {  // no prepass: zero this step's counter here (it was last read by the previous carry-over launch)
+    if (h->evC_live) KID_HIP(h, hipStreamWaitEvent(M, h->evC, 0));
+    KID_HIP(h, hipMemsetAsync(h->d_redo_cnt[0][par], 0, sizeof(int), M));
+  }
+  int *list_new = par ? h->d_redo_list2 : h->d_redo_list, *list_old = par ? h->d_redo_list : h->d_redo_list2;
+  const Redo hot{list_new, h->d_redo_cnt[0][par], 0, h->n, h->d_lane, s};
+  const Redo carry{list_old, h->d_redo_cnt[0][par ^ 1], 0, h->n, nullptr, 0};
+  const unsigned nbp = (unsigned)((h->n + 255) / 256), nbg = 4u * nbp < 2048u ? 4u * nbp : 2048u;
+  // Every record / wait is a barrier packet of ~5 us on the stream it goes to: the main stream gets one wait (in the
+  // prepass) and two records per step; with profiling on, the (start, stop) pair of the hot build doubles as the two.
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profile) { KID_HIP(h, hipEventCreate(&e0)); KID_HIP(h, hipEventCreate(&e1)); }
+  hipEvent_t evP = h->profile ? e0 : h->evP, evF = h->profile ? e1 : h->evF[0];
+  KID_HIP(h, hipEventRecord(evP, M));  // forcing records and accumulator block of this step are ready
+  KID_HIP(h, hipStreamWaitEvent(S, evP, 0));
+#define KID_LAUNCH_LANES(RKV)                                                                                                   \
+  do {                                                                                                                          \
+    if (h->carry_valid)                                                                                                         \
+      hipLaunchKernelGGL((berg_kernel<RKV, true, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, carry); \
+    /* recorded even without a carry-over launch: everything enqueued on the side stream so far (the gather of the step  \
+       before last included) is complete once the next prepass has waited for it */                                          \
+    (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
+    hipLaunchKernelGGL((berg_kernel<RKV, true, PH, true>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    (void)hipEventRecord(evF, M); (void)hipStreamWaitEvent(S, evF, 0);                                                          \
+    if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }                                                    \
+    hipLaunchKernelGGL((berg_kernel<RKV, true, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    (void)hipEventRecord(h->evG[0], S); h->evG_live[0] = true;                                                                  \
+  } while (0)
+  if (rk) KID_LAUNCH_LANES(true); else KID_LAUNCH_LANES(false);
+#undef KID_LAUNCH_LANES
+  h->carry_valid = true;
+  h->lane_step = s + 1;
   h->redo_prezeroed = false;
   KID_HIP(h, hipGetLastError());
   return KID_OK;
@@ -1115,7 +1221,10 @@ static int refresh_tables(kid_handle *h) {
     if (rc) return rc;
     hipLaunchKernelGGL(set_berg_table_kernel, dim3(1), dim3(64), 0, h->stream, h->bp, h->d_bp);
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(64), 0, h->stream, h->params, h->d_params);
-    hipLaunchKernelGGL(set_grid_kernel, dim3(1), dim3(64), 0, h->stream, dev_grid(h), h->d_grid);
+    { const int par = h->forc_parity;
+      h->forc_parity = 0; hipLaunchKernelGGL(set_grid_kernel, dim3(1), dim3(64), 0, h->stream, dev_grid(h), h->d_grid);
+      h->forc_parity = 1; hipLaunchKernelGGL(set_grid_kernel, dim3(1), dim3(64), 0, h->stream, dev_grid(h), h->d_grid2);
+      h->forc_parity = par; }
     KID_HIP(h, hipGetLastError());
     h->tables_dirty = false;
   }
@@ -1215,6 +1324,7 @@ int kid_step_local(kid_handle *h) {
   }
   if (p.old_interp_flds_order) {
     if (p.static_icebergs) rc = launch_berg<PH_THERMO | PH_SPREAD>(h);
+    else if (lanes_eligible(h)) rc = launch_berg_lanes(h);
     else rc = launch_berg<PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
   } else {
     // IB:5423: interpolate, evolve; IB:5473: interpolate again at the new position, then thermodynamics

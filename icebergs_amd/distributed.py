@@ -95,7 +95,7 @@ class PipelinedStepper:
     while the compute stream is already zeroing and filling the other block.  `flush()` joins both streams; outputs
     (kid_get_accumulators) are those of the last flushed step."""
 
-    def __init__(self, ib, params, dist=None, resort_interval=16, force_collective=False, split_general=False):
+    def __init__(self, ib, params, dist=None, resort_interval=16, force_collective=False, split_general=False, slow_lane=False):
         import torch
         self.torch, self.ib, self.params = torch, ib, params
         self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
@@ -107,21 +107,35 @@ class PipelinedStepper:
         self.comm = torch.cuda.Stream(self.dev)
         self.local_done = [torch.cuda.Event() for _ in range(2)]
         self.gather_done = [torch.cuda.Event() for _ in range(2)]
-        self.gather_reads_forcing = needs_footprint_planes(params)   # ustar reads the ocean velocity records
+        # ustar reads the ocean velocity records; with the slow-lane schedule the library double-buffers them itself
+        self.gather_reads_forcing = needs_footprint_planes(params) and not slow_lane
         # split_general: the general build (cell hops, bounces) of each half of the population also goes to the second
         # stream (kid_set_side_stream).  Measured on one MI355X it does not pay at 1e6 bergs: two half launches of the hot
         # build cost ~30 us more than one and the four cross-stream dependencies ~45 us, against ~65 us hidden.
         ib.set_stream(self.compute.cuda_stream)
-        ib.set_side_stream(self.comm.cuda_stream, bool(split_general))
+        # slow_lane: the general build (a single-wave latency) leaves the critical path altogether: bergs the hot build
+        # hands over are stepped on the second stream for two steps (kid_set_side_stream mode 2, include/kid.h)
+        ib.set_side_stream(self.comm.cuda_stream, 2 if slow_lane else (1 if split_general else 0))
         self.resort_interval, self._since_sort, self.k = resort_interval, 0, 0
+        # Slow lane: the library orders the streams itself (lanes_eligible / launch_berg_lanes in kid_hip.hip): each prepass
+        # waits for everything enqueued on the second stream up to the previous step's carry-over launch, which follows the
+        # gather of the step before; and the second stream waits for the hot build before anything of the step runs on
+        # it.  The events below would only add barrier packets (~5 us each) to the critical stream.
+        self.lib_orders = bool(slow_lane) and self._slow_lane_eligible(ib, params)
 
     def set_forcing_device(self, ptrs):
         """forcing of the step about to be taken (device addresses); applied by step() in its fused prepass"""
         self._forcing = list(ptrs)
 
+    @staticmethod
+    def _slow_lane_eligible(ib, p):
+        """mirror of lanes_eligible() in csrc/kid_hip.hip: the fused step without footloose, bonds or interactions"""
+        return bool(p.old_interp_flds_order and not p.static_icebergs and not p.mts and not p.interactive_icebergs_on
+                    and not p.footloose and not (p.grounding_fraction > 0.0) and ib.num_bergs()[0] >= 4096)
+
     def step(self):
         torch, ib, cur = self.torch, self.ib, self.k & 1
-        if self.k >= 2:
+        if self.k >= 2 and not self.lib_orders:
             self.compute.wait_event(self.gather_done[cur])   # block `cur` was last read by the gather of step k-2
         if self.gather_reads_forcing and self.k >= 1:        # the previous gather may still be reading the old records
             self.compute.wait_event(self.gather_done[(self.k - 1) & 1])
@@ -129,16 +143,19 @@ class PipelinedStepper:
         ib.set_stream(self.compute.cuda_stream)
         ib.step_prepare(getattr(self, "_forcing", None))     # forcing prepass + zeroing of block `cur`, one launch
         ib.step_local()
-        self.local_done[cur].record(self.compute)
+        if not self.lib_orders:
+            self.local_done[cur].record(self.compute)
         with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self.local_done[cur])
+            if not self.lib_orders:
+                self.comm.wait_event(self.local_done[cur])
             if self.dist is not None:
                 planes, scalars = self.views[cur]
                 self.dist.all_reduce(planes)
                 self.dist.all_reduce(scalars)
             ib.set_stream(self.comm.cuda_stream)
             ib.step_gather()
-            self.gather_done[cur].record(self.comm)
+            if not self.lib_orders:
+                self.gather_done[cur].record(self.comm)
         ib.set_stream(self.compute.cuda_stream)
         self._since_sort += 1
         if self.resort_interval and self._since_sort >= self.resort_interval:

@@ -186,7 +186,8 @@ class Icebergs:
         self._check(self.lib.kid_set_params(self.h, C.byref(params)), "kid_set_params")
 
     def set_side_stream(self, stream_ptr, enable=True):
-        self._check(self.lib.kid_set_side_stream(self.h, C.c_void_p(stream_ptr), 1 if enable else 0), "kid_set_side_stream")
+        """enable: False/0 off, True/1 two half launches, 2 the slow-lane schedule (include/kid.h)"""
+        self._check(self.lib.kid_set_side_stream(self.h, C.c_void_p(stream_ptr), int(enable)), "kid_set_side_stream")
 
     def set_stream(self, stream_ptr):
         self._check(self.lib.kid_set_stream(self.h, C.c_void_p(stream_ptr)), "kid_set_stream")

@@ -59,7 +59,13 @@ int kid_set_stream(kid_handle *h, void *hip_stream);
  * while the general build (cell hops, bounces; ~85 us of single-wave latency) of each half runs on `side_stream`, under
  * the hot build of the other half or of the next step.  Every entry point that reads berg state or accumulators on the
  * main stream first orders itself behind the side stream; a gather launched on the side stream itself is ordered by
- * that stream (icebergs_amd/distributed.py PipelinedStepper).  Results do not depend on the setting. */
+ * that stream (icebergs_amd/distributed.py PipelinedStepper).  Results do not depend on the setting.
+ * enable = 2, the "slow lane" schedule: the hot build stays one launch; a berg it hands over at step s is stepped by
+ * general-build launches on `side_stream` for steps s and s+1 (under the hot builds of s+1 and s+2) and returns to the
+ * hot build at s+2, so the general build's latency never sits between two hot builds.  The caller alternates two
+ * accumulator blocks (kid_bind_accum_buffer) and launches the gather on the side stream; the per-cell forcing records
+ * are double-buffered inside.  Applies to the fused RK4/Verlet step without footloose, bonds or interactions and falls
+ * back to the plain schedule otherwise. */
 int kid_set_side_stream(kid_handle *h, void *side_stream, int enable);
 int kid_sync(kid_handle *h);
 const char *kid_last_error(const kid_handle *h);

@@ -3,6 +3,8 @@
 Tolerances (SURVEY.md 8d / BASELINE.json): trajectories and berg sizes 1e-10 relative, per-cell fields 1e-9
 relative to the field max; cell indices, the set of surviving bergs and event counters exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -285,7 +287,7 @@ def test_c4_mts_dem(oracle, case):
         assert (refbd["broken"] != 0).sum() > 0  # the case does fracture
 
 
-@pytest.mark.parametrize("split_general", [False, True])
+@pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag"])
 def test_pipelined_stepper_matches_plain(oracle, split_general):
     """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)
     must give what the plain sequence gives; run here on one GPU, with and without a (world-size-1) RCCL all-reduce."""
@@ -294,10 +296,19 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
     from icebergs_amd.distributed import ShardedStepper, PipelinedStepper
     from icebergs_amd import types as T
     grid, p, b = S.config_c2(n=30000, seed=21, continents=True)
+    slow_lane = isinstance(split_general, str)
+    if split_general == "slow_lane_diag":   # every diagnostic plane on: the gather reads the forcing records too
+        S.set_diag_all(p)
     nsteps = 37
     dev = torch.device("cuda", 0)
     forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
     ptrs = [t.data_ptr() for t in forcing_dev]
+    # a second forcing set, used on odd steps: launches of step k still in flight must keep seeing step k's records
+    forcing_alt = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name] * (0.5 if name in ("uo", "vo", "ua", "va") else 1.0))).to(dev)
+                   for name in T.FORCING_NAMES]
+    ptrs_alt = [t.data_ptr() for t in forcing_alt]
+    if os.environ.get("KID_TEST_CONST_FORCING"):
+        ptrs_alt = ptrs
 
     def run(kind):
         ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
@@ -309,13 +320,13 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
                 acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
                 ib.bind_accum_buffer(acc_t.data_ptr(), count)
                 st = ShardedStepper(ib, acc_t, ib.ncell, p.diag_mask, None, params=p)
-                for _ in range(nsteps):
-                    st.set_forcing_device(ptrs)
+                for k in range(nsteps):
+                    st.set_forcing_device(ptrs_alt if (k & 1) else ptrs)
                     st.step()
             else:
-                st = PipelinedStepper(ib, p, None, split_general=split_general)
-                for _ in range(nsteps):
-                    st.set_forcing_device(ptrs)
+                st = PipelinedStepper(ib, p, None, split_general=(split_general is True), slow_lane=slow_lane)
+                for k in range(nsteps):
+                    st.set_forcing_device(ptrs_alt if (k & 1) else ptrs)
                     st.step()
             st.flush()
             torch.cuda.synchronize()

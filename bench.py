@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce and the gather on the critical path")
     ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
+    ap.add_argument("--resort", type=int, default=16, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
     ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)
@@ -102,12 +103,12 @@ def main():
     if pipelined:
         # the all-reduce (N>1) and the gather of step k run on a second stream under the per-berg kernels of step k+1;
         # slow lane: so do the general-build launches (bergs that crossed a cell edge or bounced)
-        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective, split_general=args.split_general, slow_lane=slow_lane)
+        stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective, split_general=args.split_general, slow_lane=slow_lane, resort_interval=args.resort)
         nreduced = stepper.views[0][0].numel()
     else:
         acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
         ib.bind_accum_buffer(acc_t.data_ptr(), count)
-        stepper = ShardedStepper(ib, acc_t, ib.ncell, params.diag_mask, dist, params=params, force_collective=args.force_collective)
+        stepper = ShardedStepper(ib, acc_t, ib.ncell, params.diag_mask, dist, params=params, force_collective=args.force_collective, resort_interval=args.resort)
         nreduced = stepper.planes.numel()
 
     def step():

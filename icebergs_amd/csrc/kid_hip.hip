@@ -406,6 +406,39 @@ __global__ void __launch_bounds__(256) cell_key_kernel(const int32_t *ine, const
     idx[k] = (unsigned)k;
   }
 }
+// Counting sort by cell for kid_move_berg_between_cells: (1) key + rank of every berg within its cell (one atomic per
+// berg on the cell's counter), (2) exclusive scan of the counters, (3) destination row = cell start + rank.  Three small
+// launches instead of the ~20 of a comparison sort of 1e6 pairs; the order of the bergs inside a cell is the order the
+// atomics arrive in (results never depend on the row order, see kid.h).
+__global__ void __launch_bounds__(256) cell_rank_kernel(const int32_t *ine, const int32_t *jne, const int32_t *alive, int isd, int jsd, int ni,
+                                                        unsigned dead_key, unsigned *key, unsigned *rank, unsigned *hist, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n) {
+    const unsigned c = alive[k] ? (unsigned)((ine[k] - isd) + (jne[k] - jsd) * ni) : dead_key;
+    key[k] = c;
+    rank[k] = atomicAdd(hist + c, 1u);
+  }
+}
+__global__ void __launch_bounds__(256) cell_place_kernel(const unsigned *key, const unsigned *rank, const unsigned *start, unsigned *perm, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k < n) perm[start[key[k]] + rank[k]] = (unsigned)k;
+}
+// every field of the SoA through the permutation in ONE launch: a thread owns a destination row, reads the source row
+// number once and walks the fields (the loads of consecutive fields are independent)
+enum { KID_PERM_MAX = KID_NB_F64 + KID_NB_I32 + 1 };
+struct PermTable { const void *src[KID_PERM_MAX]; void *dst[KID_PERM_MAX]; int n8, n4; };  // entries [0, n8) are 8-byte fields, [n8, n8 + n4) 4-byte
+__global__ void __launch_bounds__(256) permute_all_kernel(const PermTable t, const unsigned *perm, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k >= n) return;
+  const unsigned p = perm[k];
+  int f = 0;
+  for (; f + 4 <= t.n8; f += 4) {
+    const double a = ((const double *)t.src[f])[p], b = ((const double *)t.src[f + 1])[p], c = ((const double *)t.src[f + 2])[p], d = ((const double *)t.src[f + 3])[p];
+    ((double *)t.dst[f])[k] = a; ((double *)t.dst[f + 1])[k] = b; ((double *)t.dst[f + 2])[k] = c; ((double *)t.dst[f + 3])[k] = d;
+  }
+  for (; f < t.n8; ++f) ((double *)t.dst[f])[k] = ((const double *)t.src[f])[p];
+  for (; f < t.n8 + t.n4; ++f) ((int32_t *)t.dst[f])[k] = ((const int32_t *)t.src[f])[p];
+}
 template <typename TT>
 __global__ void __launch_bounds__(256) permute_kernel(const TT *src, TT *dst, const unsigned *perm, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
@@ -463,6 +496,8 @@ struct kid_handle {
   unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
   void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_perm_spare = nullptr;
+  BergPtrs bp_alt{};            // second set of field arrays: the re-binning writes all fields there in one launch, then swaps
+  unsigned *d_cell_hist = nullptr; void *d_cscan_tmp = nullptr; size_t cscan_tmp_bytes = 0; bool stable_resort = false;
   int resort_interval = 16, steps_since_sort = 0;
   // multiple time stepping / DEM
   MtsDev mts{}; MtsDev *d_mts = nullptr;
@@ -669,6 +704,11 @@ int kid_destroy(kid_handle *h) {
   for (int q = 0; q < 2; ++q) { if (h->d_key[q]) (void)hipFree(h->d_key[q]); if (h->d_idx[q]) (void)hipFree(h->d_idx[q]); }
   if (h->d_sort_tmp) (void)hipFree(h->d_sort_tmp);
   if (h->d_perm_spare) (void)hipFree(h->d_perm_spare);
+  for (auto &q : h->bp_alt.f) if (q) (void)hipFree(q);
+  for (auto &q : h->bp_alt.i) if (q) (void)hipFree(q);
+  if (h->bp_alt.id) (void)hipFree(h->bp_alt.id);
+  if (h->d_cell_hist) (void)hipFree(h->d_cell_hist);
+  if (h->d_cscan_tmp) (void)hipFree(h->d_cscan_tmp);
   if (h->d_iceberg_counter) (void)hipFree(h->d_iceberg_counter);
   if (h->d_fl_cursor) (void)hipFree(h->d_fl_cursor);
   mts_free(h);
@@ -994,8 +1034,11 @@ static bool field_never_written(const kid_handle *h, int f) {
 }
 
 // move_berg_between_cells (IB:5437, FW:1758-1797): re-bin the bergs after they moved.  With per-cell linked lists
-// that is list surgery; on the SoA it is a stable device radix sort by cell index (j-major, i-minor: the reference's
-// traversal order, IB:7106) followed by a gather of every field.  Dead bergs sort to the end and are dropped.
+// that is list surgery; on the SoA it is a device counting sort by cell index (j-major, i-minor: the reference's
+// traversal order, IB:7106) followed by ONE launch that gathers every field into a second set of arrays, which then
+// becomes the SoA.  Dead bergs sort to the end and are dropped.  The order inside a cell is arbitrary (the bonded /
+// MTS path, where it matters, builds its own order every step and never re-bins); KID_STABLE_RESORT=1 in the
+// environment selects a stable comparison sort instead.
 // Correctness never depends on it (the kernels accept any order); speed does: the hot build shares LDS cell
 // packets and atomics between the lanes of a wave that sit in the same cell.
 int kid_move_berg_between_cells(kid_handle *h) {
@@ -1007,39 +1050,55 @@ int kid_move_berg_between_cells(kid_handle *h) {
   if (h->have_bonds) { h->err = "bergs with bonds keep their rows: no re-binning while bond tables exist"; return KID_EUNSUPPORTED; }
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
+  const unsigned dead_key = (unsigned)h->ncell;  // larger than any cell index
   if (!h->d_key[0]) {
+    h->stable_resort = getenv("KID_STABLE_RESORT") != nullptr;  // a stable comparison sort keeps the row order inside a cell
     for (int q = 0; q < 2; ++q) {
       KID_HIP(h, hipMalloc(&h->d_key[q], (size_t)h->capacity * sizeof(unsigned)));
       KID_HIP(h, hipMalloc(&h->d_idx[q], (size_t)h->capacity * sizeof(unsigned)));
     }
-    KID_HIP(h, hipMalloc(&h->d_perm_spare, (size_t)h->capacity * sizeof(double)));
     size_t tmp = 0;
     KID_HIP(h, rocprim::radix_sort_pairs(nullptr, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)h->capacity, 0u, 32u, h->stream));
     h->sort_tmp_bytes = tmp;
     KID_HIP(h, hipMalloc(&h->d_sort_tmp, tmp));
+    KID_HIP(h, hipMalloc(&h->d_cell_hist, ((size_t)h->ncell + 1) * sizeof(unsigned)));
+    tmp = 0;
+    KID_HIP(h, rocprim::exclusive_scan(nullptr, tmp, h->d_cell_hist, h->d_cell_hist, 0u, (size_t)h->ncell + 1, rocprim::plus<unsigned>(), h->stream));
+    h->cscan_tmp_bytes = tmp;
+    KID_HIP(h, hipMalloc(&h->d_cscan_tmp, tmp ? tmp : 8));
+    for (int f = 0; f < KID_NB_F64; ++f) KID_HIP(h, hipMalloc(&h->bp_alt.f[f], (size_t)h->capacity * sizeof(double)));
+    for (int f = 0; f < KID_NB_I32; ++f) KID_HIP(h, hipMalloc(&h->bp_alt.i[f], (size_t)h->capacity * sizeof(int32_t)));
+    KID_HIP(h, hipMalloc(&h->bp_alt.id, (size_t)h->capacity * sizeof(int64_t)));
   }
-  const unsigned dead_key = (unsigned)h->ncell;  // larger than any cell index
-  unsigned bits = 1; while ((1ull << bits) <= (unsigned long long)dead_key) ++bits;
-  hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], h->bp.i[KID_BI_ALIVE],
-                     h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_idx[0], n);
-  size_t tmp = h->sort_tmp_bytes;
-  KID_HIP(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)n, 0u, bits, h->stream));
-  const unsigned *perm = h->d_idx[1];
+  const unsigned *perm = nullptr;
+  if (h->stable_resort) {
+    unsigned bits = 1; while ((1ull << bits) <= (unsigned long long)dead_key) ++bits;
+    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], h->bp.i[KID_BI_ALIVE],
+                       h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_idx[0], n);
+    size_t tmp = h->sort_tmp_bytes;
+    KID_HIP(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)n, 0u, bits, h->stream));
+    perm = h->d_idx[1];
+  } else {
+    KID_HIP(h, hipMemsetAsync(h->d_cell_hist, 0, ((size_t)h->ncell + 1) * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], h->bp.i[KID_BI_ALIVE],
+                       h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_key[1], h->d_cell_hist, n);
+    size_t tmp = h->cscan_tmp_bytes;
+    KID_HIP(h, rocprim::exclusive_scan(h->d_cscan_tmp, tmp, h->d_cell_hist, h->d_cell_hist, 0u, (size_t)h->ncell + 1, rocprim::plus<unsigned>(), h->stream));
+    hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, h->stream, h->d_key[0], h->d_key[1], h->d_cell_hist, h->d_idx[1], n);
+    perm = h->d_idx[1];
+  }
+  PermTable t{};
+  int moved_f[KID_NB_F64], nmf = 0;
   for (int f = 0; f < KID_NB_F64; ++f) {
     if (!h->uploaded_nonzero[f] && field_never_written(h, f)) continue;  // all zeros, before and after
-    hipLaunchKernelGGL(permute_kernel<double>, dim3(nb), dim3(256), 0, h->stream, h->bp.f[f], h->d_perm_spare, perm, n);
-    std::swap(h->bp.f[f], h->d_perm_spare);
+    t.src[t.n8] = h->bp.f[f]; t.dst[t.n8] = h->bp_alt.f[f]; ++t.n8; moved_f[nmf++] = f;
   }
-  {
-    int64_t *spare = (int64_t *)h->d_perm_spare;
-    hipLaunchKernelGGL(permute_kernel<int64_t>, dim3(nb), dim3(256), 0, h->stream, h->bp.id, spare, perm, n);
-    double *old = (double *)h->bp.id; h->bp.id = spare; h->d_perm_spare = old;
-  }
-  for (int f = 0; f < KID_NB_I32; ++f) {
-    int32_t *spare = (int32_t *)h->d_key[0];  // keys are no longer needed: reuse as the int32 spare
-    hipLaunchKernelGGL(permute_kernel<int32_t>, dim3(nb), dim3(256), 0, h->stream, h->bp.i[f], spare, perm, n);
-    unsigned *old = (unsigned *)h->bp.i[f]; h->bp.i[f] = spare; h->d_key[0] = old;
-  }
+  t.src[t.n8] = h->bp.id; t.dst[t.n8] = h->bp_alt.id; ++t.n8;
+  for (int f = 0; f < KID_NB_I32; ++f) { t.src[t.n8 + t.n4] = h->bp.i[f]; t.dst[t.n8 + t.n4] = h->bp_alt.i[f]; ++t.n4; }
+  hipLaunchKernelGGL(permute_all_kernel, dim3(nb), dim3(256), 0, h->stream, t, perm, n);
+  for (int q = 0; q < nmf; ++q) std::swap(h->bp.f[moved_f[q]], h->bp_alt.f[moved_f[q]]);
+  std::swap(h->bp.id, h->bp_alt.id);
+  for (int f = 0; f < KID_NB_I32; ++f) std::swap(h->bp.i[f], h->bp_alt.i[f]);
   KID_HIP(h, hipGetLastError());
   // the dead sorted to the tail; they are dropped the next time the host asks for the count (no synchronisation here)
   h->tail_valid = true;

@@ -84,7 +84,7 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host);        /* sets th
 int kid_download_bergs(kid_handle *h, kid_berg_soa *host);            /* host->n must be >= kid_num_bergs slots */
 int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive); /* slots include dead bergs until compaction */
 int kid_compact_bergs(kid_handle *h);                                 /* drop melted / departed bergs, keep order */
-/* move_berg_between_cells (IB:5437): stable device sort of the SoA by cell (j-major), dead bergs dropped.  Results
+/* move_berg_between_cells (IB:5437): device counting sort of the SoA by cell (j-major), dead bergs dropped.  Results
  * never depend on it, speed does.  kid_run_step calls it every `steps` steps (default 16; 0 = never). */
 int kid_move_berg_between_cells(kid_handle *h);
 int kid_set_resort_interval(kid_handle *h, int steps);

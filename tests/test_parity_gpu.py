@@ -287,7 +287,7 @@ def test_c4_mts_dem(oracle, case):
         assert (refbd["broken"] != 0).sum() > 0  # the case does fracture
 
 
-@pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag"])
+@pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag", "slow_lane_verlet"])
 def test_pipelined_stepper_matches_plain(oracle, split_general):
     """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)
     must give what the plain sequence gives; run here on one GPU, with and without a (world-size-1) RCCL all-reduce."""
@@ -299,6 +299,8 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
     slow_lane = isinstance(split_general, str)
     if split_general == "slow_lane_diag":   # every diagnostic plane on: the gather reads the forcing records too
         S.set_diag_all(p)
+    if split_general == "slow_lane_verlet":
+        p.Runge_not_Verlet = 0
     nsteps = 37
     dev = torch.device("cuda", 0)
     forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]

@@ -413,11 +413,22 @@ __global__ void __launch_bounds__(256) cell_key_kernel(const int32_t *ine, const
 __global__ void __launch_bounds__(256) cell_rank_kernel(const int32_t *ine, const int32_t *jne, const int32_t *alive, int isd, int jsd, int ni,
                                                         unsigned dead_key, unsigned *key, unsigned *rank, unsigned *hist, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
-  if (k < n) {
-    const unsigned c = alive[k] ? (unsigned)((ine[k] - isd) + (jne[k] - jsd) * ni) : dead_key;
-    key[k] = c;
-    rank[k] = atomicAdd(hist + c, 1u);
-  }
+  const bool in = k < n;
+  const unsigned c = in ? (alive[k] ? (unsigned)((ine[k] - isd) + (jne[k] - jsd) * ni) : dead_key) : 0xffffffffu;
+  // the SoA is almost sorted: the lanes of a wave form a few runs of equal cell.  One atomic per run (its head lane
+  // adds the run length), not one per berg: ~14 lanes would otherwise queue on the same address.
+  const int lane = (int)__lane_id();
+  const unsigned prev = __shfl_up(c, 1);
+  const bool head = (lane == 0) || (prev != c);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));   // heads at or below this lane
+  const int head_lane = 63 - __clzll(below);
+  const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));                  // heads after this lane
+  const int next_head = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+  unsigned base = 0u;
+  if (head && in) base = atomicAdd(hist + c, (unsigned)(next_head - lane));
+  base = __shfl(base, head_lane);
+  if (in) { key[k] = c; rank[k] = base + (unsigned)(lane - head_lane); }
 }
 __global__ void __launch_bounds__(256) cell_place_kernel(const unsigned *key, const unsigned *rank, const unsigned *start, unsigned *perm, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;

@@ -122,6 +122,13 @@ class PipelinedStepper:
         # gather of the step before; and the second stream waits for the hot build before anything of the step runs on
         # it.  The events below would only add barrier packets (~5 us each) to the critical stream.
         self.lib_orders = bool(slow_lane) and self._slow_lane_eligible(ib, params)
+        # Slow lane with an exchange (N > 1): the second stream already carries two general-build launches per step
+        # (~130 us); the all-reduce and the gather go to a third stream so that neither queue comes near the ~320 us
+        # period of the hot builds.  One more barrier on the main stream: the block must not be zeroed under its gather.
+        self.three = self.lib_orders and self.dist is not None
+        if self.three:
+            self.xchg = torch.cuda.Stream(self.dev)
+            self.new_done = [torch.cuda.Event() for _ in range(2)]
 
     def set_forcing_device(self, ptrs):
         """forcing of the step about to be taken (device addresses); applied by step() in its fused prepass"""
@@ -135,7 +142,7 @@ class PipelinedStepper:
 
     def step(self):
         torch, ib, cur = self.torch, self.ib, self.k & 1
-        if self.k >= 2 and not self.lib_orders:
+        if self.k >= 2 and (self.three or not self.lib_orders):
             self.compute.wait_event(self.gather_done[cur])   # block `cur` was last read by the gather of step k-2
         if self.gather_reads_forcing and self.k >= 1:        # the previous gather may still be reading the old records
             self.compute.wait_event(self.gather_done[(self.k - 1) & 1])
@@ -143,6 +150,19 @@ class PipelinedStepper:
         ib.set_stream(self.compute.cuda_stream)
         ib.step_prepare(getattr(self, "_forcing", None))     # forcing prepass + zeroing of block `cur`, one launch
         ib.step_local()
+        if self.three:
+            self.new_done[cur].record(self.comm)            # behind the general-build launches of this step
+            with torch.cuda.stream(self.xchg):
+                self.xchg.wait_event(self.new_done[cur])
+                planes, scalars = self.views[cur]
+                self.dist.all_reduce(planes)
+                self.dist.all_reduce(scalars)
+                ib.set_stream(self.xchg.cuda_stream)
+                ib.step_gather()
+                self.gather_done[cur].record(self.xchg)
+            ib.set_stream(self.compute.cuda_stream)
+            self._after_step()
+            return
         if not self.lib_orders:
             self.local_done[cur].record(self.compute)
         with torch.cuda.stream(self.comm):
@@ -157,12 +177,17 @@ class PipelinedStepper:
             if not self.lib_orders:
                 self.gather_done[cur].record(self.comm)
         ib.set_stream(self.compute.cuda_stream)
+        self._after_step()
+
+    def _after_step(self):
         self._since_sort += 1
         if self.resort_interval and self._since_sort >= self.resort_interval:
-            ib.move_berg_between_cells()
+            self.ib.move_berg_between_cells()
             self._since_sort = 0
         self.k += 1
 
     def flush(self):
+        if getattr(self, "three", False):
+            self.xchg.synchronize()
         self.comm.synchronize()
         self.compute.synchronize()

@@ -340,6 +340,57 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
     P.compare(ref, got, "pipelined vs plain", params=p)
 
 
+def test_slow_lane_with_collective_matches_plain(oracle):
+    """the N>1 code path of the slow-lane schedule (RCCL all-reduce + gather on a third stream), rehearsed with one
+    rank: must give what the serial single-stream sequence gives"""
+    import torch
+    import torch.distributed as dist
+    from icebergs_amd.framework import Icebergs
+    from icebergs_amd.distributed import ShardedStepper, PipelinedStepper
+    from icebergs_amd import types as T
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        grid, p, b = S.config_c2(n=30000, seed=23, continents=True)
+        S.set_diag_all(p)
+        nsteps = 35
+        dev = torch.device("cuda", 0)
+        forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
+        ptrs = [t.data_ptr() for t in forcing_dev]
+
+        def run(kind):
+            ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
+            try:
+                ib.set_stream(torch.cuda.current_stream().cuda_stream)
+                ib.upload_bergs(b)
+                if kind == "plain":
+                    _, count = ib.accum_device_ptr()
+                    acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
+                    ib.bind_accum_buffer(acc_t.data_ptr(), count)
+                    st = ShardedStepper(ib, acc_t, ib.ncell, p.diag_mask, None, params=p)
+                else:
+                    st = PipelinedStepper(ib, p, dist, force_collective=True, slow_lane=True)
+                    assert st.three
+                for _ in range(nsteps):
+                    st.set_forcing_device(ptrs)
+                    st.step()
+                st.flush()
+                torch.cuda.synchronize()
+                acc, out, scal = ib.fetch()
+                return ib.download_bergs(), acc.copy(), out.copy(), scal.copy()
+            finally:
+                ib.close()
+        ref, got = run("plain"), run("slow_lane+collective")
+        P.compare(ref, got, "slow lane + collective vs plain", params=p)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("verlet", [False, True])
 def test_polar_cap(oracle, verlet):
     """Bergs between 85N and the pole on a lat-lon grid whose top row of cells touches 90N: the tangent-plane branch

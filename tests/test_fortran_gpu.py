@@ -102,3 +102,95 @@ def test_fortran_driver_reports_errors(tmp_path):
     r = subprocess.run([REPLAY, case, res], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "tidal_drift" in (r.stderr + r.stdout)
+
+
+COUPLE = os.path.join(ROOT, "icebergs_amd", "fortran", "kid_couple")
+MAGIC2 = 1263093762
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("staggers", [("B", "B"), ("C", "A")])
+def test_fortran_coupling_front_end(oracle, tmp_path, staggers):
+    """forcing ingest + calving + step through the Fortran module (kid_couple.F90 stands where the coupler stands) must
+    reproduce the oracle's ko_ingest_forcing / ko_calving / ko_run_step sequence"""
+    import oracle_lib as O
+    subprocess.run(["make", "-s", "-C", os.path.dirname(COUPLE)], check=True)
+    vs, ss = staggers
+    grid = S.c2_forcing(S.latlon_grid(ni=60, nj=200, dlon=6.0))
+    p = S.default_params()
+    p.current_year, p.current_yearday = 3, 41.5
+    b = S.place_bergs(grid, 300, 5, (3, 57), (3, 197))
+    cp = S.calving_params(p)
+    ncalls, cap = 4, 12000
+    st_code = {"B": T.ENUMS["KID_BGRID_NE"], "C": T.ENUMS["KID_CGRID_NE"], "A": T.ENUMS["KID_AGRID"]}
+    calls = []
+    for k in range(ncalls):
+        a = S.coupler_forcing(grid, seed=30 + k, vel_stagger=vs, stress_stagger=ss, kelvin=(k % 2 == 0), sss=True)
+        a["calving"], a["calving_hflx"] = S.coupler_calving(grid, seed=k % 2, frac=0.04)
+        calls.append(a)
+    case, res = str(tmp_path / "couple.bin"), str(tmp_path / "couple_res.bin")
+    n = len(b["lon"])
+    with open(case, "wb") as f:
+        f.write(struct.pack("<i", MAGIC2))
+        f.write(bytes(grid["desc"])); f.write(bytes(p)); f.write(bytes(cp))
+        f.write(struct.pack("<6i", st_code[vs], st_code[ss], 0, 1, 1, ncalls))
+        a0 = calls[0]
+        f.write(struct.pack("<8i", a0["uo"].shape[1], a0["uo"].shape[0], a0["vo"].shape[1], a0["vo"].shape[0],
+                            a0["tauxa"].shape[1], a0["tauxa"].shape[0], a0["tauya"].shape[1], a0["tauya"].shape[0]))
+        f.write(struct.pack("<qq", n, cap))
+        for name in T.GRID_STATIC_NAMES:
+            f.write(np.ascontiguousarray(grid["static"][name], dtype=np.float64).tobytes())
+        for name in T.BERG_F64_NAMES:
+            f.write(b[name].tobytes())
+        for name in T.BERG_I32_NAMES:
+            f.write(b[name].tobytes())
+        f.write(b["id"].tobytes())
+        for a in calls:
+            for name in ("uo", "ui", "vo", "vi", "tauxa", "tauya", "ssh", "cn", "hi", "sst", "sss", "calving", "calving_hflx"):
+                f.write(np.ascontiguousarray(a[name], dtype=np.float64).tobytes())
+    r = subprocess.run([COUPLE, case, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    # the same sequence on the oracle
+    orc = O.Oracle(grid, p)
+    stc = orc.new_calving_state()
+    bergs = S.empty_bergs(cap)
+    for k_, v in b.items():
+        bergs[k_][:n] = v
+    bergs["alive"][n:] = 0
+    bergs["_n"] = n
+    planes = None
+    for a in calls:
+        planes = orc.ingest_forcing(a, vel_stagger=vs, stress_stagger=ss, cyclic_x=True, planes=planes)
+        orc.set_forcing(planes)
+        rc, rscal = orc.calving(cp, a["calving"], a["calving_hflx"], stc, bergs, cap)
+        assert rc == 0
+        orc.run_step(bergs, 1)
+    d = grid["desc"]
+    ni, nj, nk = d.ied - d.isd + 1, d.jed - d.jsd + 1, T.ENUMS["KID_NCLASSES"]
+    with open(res, "rb") as f:
+        rd = lambda cnt: np.frombuffer(f.read(8 * cnt), dtype=np.float64).copy()
+        gplanes = rd(T.ENUMS["KID_NFORCING"] * ni * nj).reshape(-1, nj, ni)
+        g_ice = rd(nk * ni * nj).reshape(nk, nj, ni)
+        g_heat = rd(ni * nj).reshape(nj, ni)
+        g_real = rd(nk * ni * nj).reshape(nk, nj, ni)
+        g_calv, g_hflx = rd(ni * nj).reshape(nj, ni), rd(ni * nj).reshape(nj, ni)
+        gscal = rd(T.ENUMS["KID_NCALV_SCALARS"])
+        nslots = struct.unpack("<q", f.read(8))[0]
+        gb = {name: rd(nslots) for name in T.BERG_F64_NAMES}
+        for name in T.BERG_I32_NAMES:
+            gb[name] = np.frombuffer(f.read(4 * nslots), dtype=np.int32).copy()
+        gb["id"] = np.frombuffer(f.read(8 * nslots), dtype=np.int64).copy()
+    for k_, name in enumerate(T.FORCING_NAMES):
+        assert np.array_equal(gplanes[k_], planes[name]), name
+    assert np.array_equal(g_ice, stc["stored_ice"]) and np.array_equal(g_heat, stc["stored_heat"]) and np.array_equal(g_real, stc["real_calving"])
+    assert np.array_equal(g_calv, stc["calving"]) and np.array_equal(g_hflx, stc["calving_hflx"])
+    assert np.allclose(gscal, rscal, rtol=1e-12, atol=0)
+    assert bergs["_n"] > n + 200 and nslots >= int((bergs["alive"][:bergs["_n"]] != 0).sum())
+    # surviving bergs, matched by id
+    ra = bergs["alive"][:bergs["_n"]] != 0
+    ga = gb["alive"] != 0
+    ro, go = np.argsort(bergs["id"][:bergs["_n"]][ra]), np.argsort(gb["id"][ga])
+    assert np.array_equal(bergs["id"][:bergs["_n"]][ra][ro], gb["id"][ga][go])
+    for name in ("lon", "lat", "uvel", "vvel", "mass", "thickness", "heat_density", "start_day"):
+        rv, gv = bergs[name][:bergs["_n"]][ra][ro], gb[name][ga][go]
+        assert np.allclose(gv, rv, rtol=1e-10, atol=1e-12), (name, float(np.abs(gv - rv).max()))

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce and the gather on the critical path")
     ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
-    ap.add_argument("--resort", type=int, default=16, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
+    ap.add_argument("--resort", type=int, default=12, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
     ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)

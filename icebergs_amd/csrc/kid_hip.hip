@@ -430,13 +430,18 @@ __global__ void __launch_bounds__(256) cell_rank_kernel(const int32_t *ine, cons
   base = __shfl(base, head_lane);
   if (in) { key[k] = c; rank[k] = base + (unsigned)(lane - head_lane); }
 }
-__global__ void __launch_bounds__(256) cell_place_kernel(const unsigned *key, const unsigned *rank, const unsigned *start, unsigned *perm, long long n) {
+__global__ void __launch_bounds__(256) cell_place_kernel(const unsigned *key, const unsigned *rank, const unsigned *start, unsigned *perm, unsigned *inv, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
-  if (k < n) perm[start[key[k]] + rank[k]] = (unsigned)k;
+  if (k < n) { const unsigned pos = start[key[k]] + rank[k]; perm[pos] = (unsigned)k; inv[k] = pos; }
+}
+// a list of row numbers through the re-binning (slow-lane schedule: the bergs handed over by the hot build just before it)
+__global__ void __launch_bounds__(256) translate_list_kernel(int *list, const int *count, const unsigned *inv) {
+  const int total = *count;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) list[t] = (int)inv[list[t]];
 }
 // every field of the SoA through the permutation in ONE launch: a thread owns a destination row, reads the source row
 // number once and walks the fields (the loads of consecutive fields are independent)
-enum { KID_PERM_MAX = KID_NB_F64 + KID_NB_I32 + 1 };
+enum { KID_PERM_MAX = KID_NB_F64 + KID_NB_I32 + 2 };   // every field, the ids, the lane array of the slow-lane schedule
 struct PermTable { const void *src[KID_PERM_MAX]; void *dst[KID_PERM_MAX]; int n8, n4; };  // entries [0, n8) are 8-byte fields, [n8, n8 + n4) 4-byte
 __global__ void __launch_bounds__(256) permute_all_kernel(const PermTable t, const unsigned *perm, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
@@ -499,7 +504,7 @@ struct kid_handle {
   double *d_orient = nullptr;              // bond-derived hexagon orientation per berg (mts / interacting bergs)
   hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
   // "slow lane" schedule (kid_set_side_stream mode 2, launch_berg_lanes)
-  int side_mode = 0; int *d_lane = nullptr; int lane_step = 1; bool lanes_active = false, carry_valid = false, evC_live = false;
+  int side_mode = 0; int *d_lane = nullptr, *d_lane_alt = nullptr; hipEvent_t evR = nullptr; int lane_step = 1; bool lanes_active = false, carry_valid = false, evC_live = false;
   hipEvent_t evC = nullptr, evP = nullptr;
   VelRec *d_vel2 = nullptr; TrcRec *d_trc2 = nullptr; DevGrid *d_grid2 = nullptr; int forc_parity = 0;  // forcing records of the odd steps
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
@@ -710,6 +715,8 @@ int kid_destroy(kid_handle *h) {
   if (h->d_vel2) (void)hipFree(h->d_vel2);
   if (h->d_trc2) (void)hipFree(h->d_trc2);
   if (h->d_lane) (void)hipFree(h->d_lane);
+  if (h->d_lane_alt) (void)hipFree(h->d_lane_alt);
+  if (h->evR) (void)hipEventDestroy(h->evR);
   if (h->evC) (void)hipEventDestroy(h->evC);
   if (h->evP) (void)hipEventDestroy(h->evP);
   for (int q = 0; q < 2; ++q) { if (h->d_key[q]) (void)hipFree(h->d_key[q]); if (h->d_idx[q]) (void)hipFree(h->d_idx[q]); }
@@ -1052,6 +1059,7 @@ static bool field_never_written(const kid_handle *h, int f) {
 // environment selects a stable comparison sort instead.
 // Correctness never depends on it (the kernels accept any order); speed does: the hot build shares LDS cell
 // packets and atomics between the lanes of a wave that sit in the same cell.
+static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_count);
 int kid_move_berg_between_cells(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
@@ -1059,6 +1067,14 @@ int kid_move_berg_between_cells(kid_handle *h) {
   h->steps_since_sort = 0;
   if (h->n == 0) return KID_OK;
   if (h->have_bonds) { h->err = "bergs with bonds keep their rows: no re-binning while bond tables exist"; return KID_EUNSUPPORTED; }
+  const int rc = rebin_core(h, false, nullptr, nullptr);
+  if (rc) return rc;
+  // the dead sorted to the tail; they are dropped the next time the host asks for the count (no synchronisation here)
+  h->tail_valid = true;
+  return KID_OK;
+}
+// with_lane: the lane array moves with the rows and `list` (row numbers, *list_count of them) is translated
+static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_count) {
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
   const unsigned dead_key = (unsigned)h->ncell;  // larger than any cell index
@@ -1095,7 +1111,7 @@ int kid_move_berg_between_cells(kid_handle *h) {
                        h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_key[1], h->d_cell_hist, n);
     size_t tmp = h->cscan_tmp_bytes;
     KID_HIP(h, rocprim::exclusive_scan(h->d_cscan_tmp, tmp, h->d_cell_hist, h->d_cell_hist, 0u, (size_t)h->ncell + 1, rocprim::plus<unsigned>(), h->stream));
-    hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, h->stream, h->d_key[0], h->d_key[1], h->d_cell_hist, h->d_idx[1], n);
+    hipLaunchKernelGGL(cell_place_kernel, dim3(nb), dim3(256), 0, h->stream, h->d_key[0], h->d_key[1], h->d_cell_hist, h->d_idx[1], h->d_idx[0], n);
     perm = h->d_idx[1];
   }
   PermTable t{};
@@ -1106,13 +1122,20 @@ int kid_move_berg_between_cells(kid_handle *h) {
   }
   t.src[t.n8] = h->bp.id; t.dst[t.n8] = h->bp_alt.id; ++t.n8;
   for (int f = 0; f < KID_NB_I32; ++f) { t.src[t.n8 + t.n4] = h->bp.i[f]; t.dst[t.n8 + t.n4] = h->bp_alt.i[f]; ++t.n4; }
+  if (with_lane) {
+    if (h->stable_resort) { h->err = "KID_STABLE_RESORT has no inverse permutation for the slow-lane re-binning"; return KID_EUNSUPPORTED; }
+    if (!h->d_lane_alt) KID_HIP(h, hipMalloc(&h->d_lane_alt, (size_t)h->capacity * sizeof(int)));
+    t.src[t.n8 + t.n4] = h->d_lane; t.dst[t.n8 + t.n4] = h->d_lane_alt; ++t.n4;
+  }
   hipLaunchKernelGGL(permute_all_kernel, dim3(nb), dim3(256), 0, h->stream, t, perm, n);
+  if (with_lane) {
+    std::swap(h->d_lane, h->d_lane_alt);
+    if (list) hipLaunchKernelGGL(translate_list_kernel, dim3(64), dim3(256), 0, h->stream, list, list_count, h->d_idx[0]);
+  }
   for (int q = 0; q < nmf; ++q) std::swap(h->bp.f[moved_f[q]], h->bp_alt.f[moved_f[q]]);
   std::swap(h->bp.id, h->bp_alt.id);
   for (int f = 0; f < KID_NB_I32; ++f) std::swap(h->bp.i[f], h->bp_alt.i[f]);
   KID_HIP(h, hipGetLastError());
-  // the dead sorted to the tail; they are dropped the next time the host asks for the count (no synchronisation here)
-  h->tail_valid = true;
   h->tables_dirty = true;
   return refresh_tables(h);
 }
@@ -1243,13 +1266,26 @@ static int launch_berg_lanes(kid_handle *h) {
        before last included) is complete once the next prepass has waited for it */                                          \
     (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
     hipLaunchKernelGGL((berg_kernel<RKV, true, PH, true>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
-    (void)hipEventRecord(evF, M); (void)hipStreamWaitEvent(S, evF, 0);                                                          \
+    (void)hipEventRecord(evF, M);                                                                                               \
     if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }                                                    \
+    if (rebin_now) {                                                                                                            \
+      /* re-binning inside the step: between the hot build and the general build of the bergs it handed over, whose list  \
+         and lanes move with the rows; nothing is drained and no latency is exposed (the carry-over launch of this step   \
+         is long finished, the main stream only has to say so before it moves rows) */                                      \
+      (void)hipStreamWaitEvent(M, h->evC, 0);                                                                                   \
+      rebin_rc = rebin_core(h, true, list_new, h->d_redo_cnt[0][par]);                                                          \
+      if (!h->evR) (void)hipEventCreateWithFlags(&h->evR, hipEventDisableTiming);                                               \
+      (void)hipEventRecord(h->evR, M); (void)hipStreamWaitEvent(S, h->evR, 0);                                                  \
+    } else (void)hipStreamWaitEvent(S, evF, 0);                                                                                 \
     hipLaunchKernelGGL((berg_kernel<RKV, true, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(h->evG[0], S); h->evG_live[0] = true;                                                                  \
   } while (0)
+  const bool rebin_now = h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval && !h->have_bonds && getenv("KID_STABLE_RESORT") == nullptr;
+  int rebin_rc = KID_OK;
   if (rk) KID_LAUNCH_LANES(true); else KID_LAUNCH_LANES(false);
 #undef KID_LAUNCH_LANES
+  if (rebin_rc) return rebin_rc;
+  if (rebin_now) h->steps_since_sort = 0;
   h->carry_valid = true;
   h->lane_step = s + 1;
   h->redo_prezeroed = false;
@@ -1418,7 +1454,7 @@ int kid_run_step(kid_handle *h, int nsteps) {
     if (rc) return rc;
     rc = kid_step_gather(h);
     if (rc) return rc;
-    if (!h->params.mts && !h->params.interactive_icebergs_on && h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised; bonded bergs keep their rows
+    if (!h->lanes_active && !h->params.mts && !h->params.interactive_icebergs_on && h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval) {  // IB:5437, amortised; bonded bergs keep their rows
       rc = kid_move_berg_between_cells(h);
       if (rc) return rc;
     }

@@ -122,6 +122,8 @@ class PipelinedStepper:
         # gather of the step before; and the second stream waits for the hot build before anything of the step runs on
         # it.  The events below would only add barrier packets (~5 us each) to the critical stream.
         self.lib_orders = bool(slow_lane) and self._slow_lane_eligible(ib, params)
+        if self.lib_orders:
+            ib.set_resort_interval(resort_interval)
         # Slow lane with an exchange (N > 1): the second stream already carries two general-build launches per step
         # (~130 us); the all-reduce and the gather go to a third stream so that neither queue comes near the ~320 us
         # period of the hot builds.  One more barrier on the main stream: the block must not be zeroed under its gather.
@@ -181,7 +183,9 @@ class PipelinedStepper:
 
     def _after_step(self):
         self._since_sort += 1
-        if self.resort_interval and self._since_sort >= self.resort_interval:
+        if self.lib_orders:
+            pass   # slow lane: the library re-bins inside the step, between the hot build and the general build
+        elif self.resort_interval and self._since_sort >= self.resort_interval:
             self.ib.move_berg_between_cells()
             self._since_sort = 0
         self.k += 1

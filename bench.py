@@ -20,6 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The schedule uses up to three streams next to RCCL's own; the HIP runtime maps streams onto 4 hardware queues by
+# default and streams that share a queue serialise (measured: +68 us/step when the prepass shared one with the general
+# build).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ALGO_BYTES_PER_BERG_STEP = 256.0  # SURVEY.md 8d (config 2): 129 B read + 128 B written of per-berg SoA state
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

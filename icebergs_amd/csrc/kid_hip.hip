@@ -1528,3 +1528,5 @@ int kid_profile_get(kid_handle *h, double *berg_ms, int64_t *launches, double *a
 }
 
 }  // extern "C"
+
+#include "kid_restart.inc"

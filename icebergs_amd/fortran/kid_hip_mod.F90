@@ -22,6 +22,7 @@ module kid_hip_mod
   public :: kid_forcing_in, kid_ingest_forcing, kid_get_forcing, KID_BGRID_NE, KID_CGRID_NE, KID_AGRID
   public :: kid_calving_params, kid_calving_in, kid_set_calving_params, kid_set_calving_state, kid_get_calving_state
   public :: kid_calving, kid_get_calving, KID_NCALV_SCALARS, KID_NCLASSES
+  public :: kid_write_restart, kid_read_restart
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
@@ -105,6 +106,18 @@ module kid_hip_mod
     integer(c_int) function kid_get_calving(h, calving, calving_hflx) bind(C, name='kid_get_calving')
       import :: c_int, c_ptr
       type(c_ptr), value :: h, calving, calving_hflx
+    end function
+    !> write_restart_bergs / read_restart_bergs (icebergs_fms2io.F90:124-631, 663-1049) from / into the resident state;
+    !! dir is a C string (trim(restart_dir)//c_null_char)
+    integer(c_int) function kid_write_restart(h, dir) bind(C, name='kid_write_restart')
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: dir(*)
+    end function
+    integer(c_int) function kid_read_restart(h, dir) bind(C, name='kid_read_restart')
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: dir(*)
     end function
     integer(c_int) function kid_upload_bergs(h, soa) bind(C, name='kid_upload_bergs')
       import :: c_int, c_ptr, kid_berg_soa

@@ -126,6 +126,13 @@ class Icebergs:
         self._check(self.lib.kid_get_forcing(self.h, arr), "kid_get_forcing")
         return out
 
+    # ---- restart files (icebergs_fms2io.F90:124-631, 663-1049) ----
+    def write_restart(self, directory):
+        self._check(self.lib.kid_write_restart(self.h, str(directory).encode()), "kid_write_restart")
+
+    def read_restart(self, directory):
+        self._check(self.lib.kid_read_restart(self.h, str(directory).encode()), "kid_read_restart")
+
     # ---- calving source (IB:5203-5231, accumulate_calving IB:6153, calve_icebergs IB:6225) ----
     def set_calving_params(self, cp):
         self._calv_params = cp

@@ -22,6 +22,7 @@ SYMBOLS = [
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
     "kid_ingest_forcing", "kid_get_forcing",
     "kid_set_calving_params", "kid_set_calving_state", "kid_get_calving_state", "kid_calving", "kid_get_calving",
+    "kid_restart_write_bergs", "kid_restart_count_bergs", "kid_restart_read_bergs", "kid_write_restart", "kid_read_restart",
 ]
 
 
@@ -71,6 +72,11 @@ def load():
     lib.kid_get_calving_state.argtypes = [H, dp, dp, dp, dp, dp]
     lib.kid_calving.argtypes = [H, C.POINTER(T.CalvingIn), dp]
     lib.kid_get_calving.argtypes = [H, dp, dp]
+    lib.kid_restart_write_bergs.argtypes = [C.c_char_p, C.POINTER(T.Params), C.POINTER(T.BergSoA)]
+    lib.kid_restart_count_bergs.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
+    lib.kid_restart_read_bergs.argtypes = [C.c_char_p, C.POINTER(T.BergSoA), C.c_int64]
+    lib.kid_write_restart.argtypes = [H, C.c_char_p]
+    lib.kid_read_restart.argtypes = [H, C.c_char_p]
     lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_step_prepare.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.kid_set_side_stream.argtypes = [H, C.c_void_p, C.c_int]

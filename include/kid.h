@@ -12,6 +12,7 @@
  *   forcing ingest result (grd%uo ... )   IB:5236-5383     kid_set_forcing
  *   the forcing ingest block itself       IB:5236-5383     kid_ingest_forcing (+ kid_get_forcing for send_data)
  *   calving block + accumulate_calving + calve_icebergs  IB:5203-5231, 5388, 5403   kid_calving
+ *   write_restart_bergs / read_restart_bergs  IO2:124-631, 663-1049   kid_write_restart / kid_read_restart
  *   accumulator zeroing                   IB:5125-5156     kid_zero_accumulators
  *   interp_gridded_fields_to_bergs        IB:5423, 5473    kid_interp_gridded_fields_to_bergs
  *   evolve_icebergs                       IB:5433          kid_evolve_icebergs
@@ -126,6 +127,24 @@ int kid_calving(kid_handle *h, const kid_calving_in *in, double *scalars);
  * after kid_calving; data-domain planes, NULL skipped.  The melt the step adds to grd%calving_hflx (IB:3129) is the
  * accumulator KID_A_CALVING_HFLX. */
 int kid_get_calving(kid_handle *h, double *calving, double *calving_hflx);
+
+/* ---- restart files straight from the structure of arrays ----
+ * icebergs.res.nc as write_restart_bergs writes it (icebergs_fms2io.F90:124-420: one unlimited dimension "i", the same
+ * variable names, order, types and long_name / units attributes, ids split into id_cnt / id_ij) and calving.res.nc
+ * (IO2:583-631: stored_ice, stored_heat, iceberg_counter_grd, the running means).  netCDF classic (CDF-2) written and
+ * read directly: neither FMS nor libnetcdf is needed.  bonds_iceberg.res.nc is not handled yet (bonded populations
+ * are refused).
+ * The first three work on host arrays and need no device: */
+int kid_restart_write_bergs(const char *path, const kid_params *p, const kid_berg_soa *host);
+int kid_restart_count_bergs(const char *path, int64_t *n);
+/* fills the arrays of `host` (room for `capacity` rows): the file's fields, zeros elsewhere, *_old = current values and
+ * halo_berg = 0 as read_restart_bergs sets them (IO2:895-925); xi / yj need the grid and are left to kid_read_restart */
+int kid_restart_read_bergs(const char *path, kid_berg_soa *host, int64_t capacity);
+/* the resident state to <dir>/icebergs.res.nc (+ <dir>/calving.res.nc when the calving source is on), and back:
+ * bergs outside the computational domain or in cells of zero area are dropped (IO2:880-884, 948-955), xi / yj are
+ * recomputed on the device from (lon, lat, ine, jne) (IO2:945) */
+int kid_write_restart(kid_handle *h, const char *dir);
+int kid_read_restart(kid_handle *h, const char *dir);
 
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */

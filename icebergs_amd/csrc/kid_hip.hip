@@ -591,7 +591,10 @@ static int check_params(kid_handle *h, const kid_params *p) {
     if (p->max_bonds < 1 || p->max_bonds > KID_MAX_BONDS) { h->err = "max_bonds out of range"; return KID_EINVAL; }
   }
   if (p->tidal_drift > 0.) { h->err = "tidal_drift needs FMS's random stream: not supported"; return KID_EUNSUPPORTED; }
-  if (p->time_average_weight) { h->err = "time_average_weight is not implemented"; return KID_EUNSUPPORTED; }
+  // time_average_weight=T is accepted: the spreading it moves into the integrator stages (IB:7264, 7395, 7433, 7490, 7620)
+  // fills mass/area/Uvel/Vvel_on_ocean, but calculate_mass_on_ocean zeroes those planes again (IB:4984-4987) without
+  // refilling them (IB:4997), and nothing reads them in between: the reference's spread_mass is identically zero in
+  // this mode.  So the stage spreading is not launched and the spreading phase skips the berg (berg_kernel, PH_SPREAD).
   if (p->find_melt_using_spread_mass) { h->err = "find_melt_using_spread_mass is not implemented"; return KID_EUNSUPPORTED; }
   if (p->footloose && p->displace_fl_bergs) { h->err = "footloose with displace_fl_bergs needs FMS's random stream: use displace_fl_bergs=F"; return KID_EUNSUPPORTED; }
   if (p->Runge_not_Verlet && p->footloose) { h->err = "Runge_not_Verlet must be false to use footloose (FW:1485-1490)"; return KID_EINVAL; }

@@ -1404,6 +1404,7 @@ void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_
     if (!(area > 0.)) continue;
     g_orient_use = (g_orient != NULL);
     if (g_orient) g_orient_now = g_orient[k];
+    /* time_average_weight: the stage spreading of IB:7264/7395-7620 is zeroed again at IB:4984-4987 and never refilled -> nothing to spread */
     if ((p->add_weight_to_ocean && !p->time_average_weight) || p->find_melt_using_spread_mass)
       spread_mass(g, p, acc, bs, i, j, bs[KID_B_XI], bs[KID_B_YJ], bs[KID_B_MASS], bs[KID_B_MASS_OF_BITS], bs[KID_B_MASS_SCALING],
                   bs[KID_B_LENGTH] * bs[KID_B_WIDTH], bs[KID_B_THICKNESS], 1);

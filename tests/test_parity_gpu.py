@@ -340,6 +340,24 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
     P.compare(ref, got, "pipelined vs plain", params=p)
 
 
+@pytest.mark.parametrize("verlet", [False, True])
+def test_time_average_weight(oracle, verlet):
+    """time_average_weight=T: the spreading moves into the integrator stages (IB:7264, 7395-7620), calculate_mass_on_ocean
+    then zeroes those planes without refilling them (IB:4984-4997): spread_mass is identically zero in the reference,
+    and everything else goes on as before"""
+    from icebergs_amd import types as T
+    grid, p, b = S.config_c2(n=4000, seed=31, continents=True)
+    S.set_diag_all(p)
+    p.time_average_weight = 1
+    if verlet:
+        p.Runge_not_Verlet = 0
+    ref, got = _both(grid, p, b, 12, "fused")
+    P.compare(ref, got, "time_average_weight/verlet=%s" % verlet, params=p)
+    k = T.ENUMS["KID_O_SPREAD_MASS"]
+    assert not ref[2][k].any() and not got[2][k].any()
+    assert np.abs(got[1][T.ENUMS["KID_A_FLOATING_MELT"]]).max() > 0   # the melt fluxes are still there
+
+
 def test_slow_lane_with_collective_matches_plain(oracle):
     """the N>1 code path of the slow-lane schedule (RCCL all-reduce + gather on a third stream), rehearsed with one
     rank: must give what the serial single-stream sequence gives"""

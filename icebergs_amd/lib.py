@@ -22,7 +22,7 @@ SYMBOLS = [
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
     "kid_ingest_forcing", "kid_get_forcing",
     "kid_set_calving_params", "kid_set_calving_state", "kid_get_calving_state", "kid_calving", "kid_get_calving",
-    "kid_restart_write_bergs", "kid_restart_count_bergs", "kid_restart_read_bergs", "kid_write_restart", "kid_read_restart",
+    "kid_restart_write_bergs", "kid_restart_count_bergs", "kid_restart_read_bergs", "kid_restart_write_bonds", "kid_restart_read_bonds", "kid_write_restart", "kid_read_restart",
 ]
 
 
@@ -75,6 +75,8 @@ def load():
     lib.kid_restart_write_bergs.argtypes = [C.c_char_p, C.POINTER(T.Params), C.POINTER(T.BergSoA)]
     lib.kid_restart_count_bergs.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
     lib.kid_restart_read_bergs.argtypes = [C.c_char_p, C.POINTER(T.BergSoA), C.c_int64]
+    lib.kid_restart_write_bonds.argtypes = [C.c_char_p, C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(T.BondSoA)]
+    lib.kid_restart_read_bonds.argtypes = [C.c_char_p, C.POINTER(T.BergSoA), C.POINTER(T.BondSoA)]
     lib.kid_write_restart.argtypes = [H, C.c_char_p]
     lib.kid_read_restart.argtypes = [H, C.c_char_p]
     lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]

@@ -130,17 +130,22 @@ int kid_get_calving(kid_handle *h, double *calving, double *calving_hflx);
 
 /* ---- restart files straight from the structure of arrays ----
  * icebergs.res.nc as write_restart_bergs writes it (icebergs_fms2io.F90:124-420: one unlimited dimension "i", the same
- * variable names, order, types and long_name / units attributes, ids split into id_cnt / id_ij) and calving.res.nc
+ * variable names, order, types and long_name / units attributes, ids split into id_cnt / id_ij), bonds_iceberg.res.nc
+ * for bonded populations (IO2:466-583) and calving.res.nc
  * (IO2:583-631: stored_ice, stored_heat, iceberg_counter_grd, the running means).  netCDF classic (CDF-2) written and
- * read directly: neither FMS nor libnetcdf is needed.  bonds_iceberg.res.nc is not handled yet (bonded populations
- * are refused).
+ * read directly: neither FMS nor libnetcdf is needed.
  * The first three work on host arrays and need no device: */
 int kid_restart_write_bergs(const char *path, const kid_params *p, const kid_berg_soa *host);
 int kid_restart_count_bergs(const char *path, int64_t *n);
 /* fills the arrays of `host` (room for `capacity` rows): the file's fields, zeros elsewhere, *_old = current values and
  * halo_berg = 0 as read_restart_bergs sets them (IO2:895-925); xi / yj need the grid and are left to kid_read_restart */
 int kid_restart_read_bergs(const char *path, kid_berg_soa *host, int64_t capacity);
-/* the resident state to <dir>/icebergs.res.nc (+ <dir>/calving.res.nc when the calving source is on), and back:
+/* bonds_iceberg.res.nc (IO2:466-583, read_restart_bonds IO2:1190-1481): one record per bond side; `bergs` gives the ids
+ * and cells of both ends.  Reading puts every bond at the head of its berg's list, as form_a_bond does. */
+int kid_restart_write_bonds(const char *path, const kid_params *p, const kid_berg_soa *bergs, const kid_bond_soa *bonds);
+int kid_restart_read_bonds(const char *path, const kid_berg_soa *bergs, kid_bond_soa *bonds);
+/* the resident state to <dir>/icebergs.res.nc (+ bonds_iceberg.res.nc with bonds, + calving.res.nc when the calving
+ * source is on), and back:
  * bergs outside the computational domain or in cells of zero area are dropped (IO2:880-884, 948-955), xi / yj are
  * recomputed on the device from (lon, lat, ine, jne) (IO2:945) */
 int kid_write_restart(kid_handle *h, const char *dir);

@@ -194,3 +194,91 @@ def test_restart_round_trip_continues_the_run(tmp_path):
         assert np.allclose(ba[name][la][oa], br[name][lr][orr], rtol=1e-9, atol=1e-9), name
     a.close()
     r.close()
+
+
+def _bond_soa(bd, n):
+    s = T.BondSoA()
+    s.n, s.max_bonds = n, int(bd["max_bonds"])
+    s.count = bd["count"].ctypes.data_as(C.POINTER(C.c_int32))
+    s.other_id = bd["other_id"].ctypes.data_as(C.POINTER(C.c_int64))
+    s.broken = bd["broken"].ctypes.data_as(C.POINTER(C.c_int32))
+    for k, name in enumerate(T.BOND_F64_NAMES):
+        s.f64[k] = bd[name].ctypes.data_as(C.POINTER(C.c_double))
+    return s
+
+
+def test_bonds_file_on_the_host(tmp_path):
+    """bonds_iceberg.res.nc (IO2:466-583): one record per bond side, readable by scipy; reading puts every bond at the
+    head of its berg's list (form_a_bond), i.e. the slots come back in reverse"""
+    lib = L.load()
+    grid, p, b, bd = S.config_c4(nx=4, ny=5)
+    n = len(b["lon"])
+    rng = np.random.default_rng(1)
+    for name in ("tangd1", "tangd2", "nstress", "sstress", "rel_rotation"):
+        bd[name][:] = rng.normal(0, 1, bd[name].shape)
+    bd["broken"][::7] = 1
+    path = str(tmp_path / "bonds_iceberg.res.nc")
+    assert lib.kid_restart_write_bonds(path.encode(), C.byref(p), C.byref(_soa(b, n)), C.byref(_bond_soa(bd, n))) == 0
+    nb = int(bd["count"].sum())
+    with netcdf_file(path, "r", mmap=False) as f:
+        assert list(f.variables)[:8] == ["first_berg_ine", "first_berg_jne", "first_id_cnt", "first_id_ij", "other_berg_ine", "other_berg_jne", "other_id_cnt", "other_id_ij"]
+        assert list(f.variables)[8:] == ["tangd1", "tangd2", "nstress", "sstress", "rel_rotation", "broken"]
+        assert f.variables["first_id_ij"].shape == (nb,) and f.variables["broken"].typecode() == "d"
+        first = (f.variables["first_id_cnt"][:].astype(np.int64) << 32) + f.variables["first_id_ij"][:]
+        other = (f.variables["other_id_cnt"][:].astype(np.int64) << 32) + f.variables["other_id_ij"][:]
+        row = {int(i): k for k, i in enumerate(b["id"])}
+        assert all(b["ine"][row[int(o)]] == v for o, v in zip(other, f.variables["other_berg_ine"][:]))
+        k0 = int(np.argmax(bd["count"]))       # a berg with the most bonds: its records follow its slots
+        mine = np.nonzero(first == b["id"][k0])[0]
+        assert list(other[mine]) == [int(bd["other_id"][s * n + k0]) for s in range(bd["count"][k0])]
+        assert list(f.variables["tangd1"][:][mine]) == [bd["tangd1"][s * n + k0] for s in range(bd["count"][k0])]
+    back = S.empty_bonds(n, int(bd["max_bonds"]))
+    assert lib.kid_restart_read_bonds(path.encode(), C.byref(_soa(b, n)), C.byref(_bond_soa(back, n))) == 0
+    assert np.array_equal(back["count"], bd["count"])
+    for k in range(n):
+        c = int(bd["count"][k])
+        for s in range(c):
+            r = c - 1 - s
+            assert back["other_id"][s * n + k] == bd["other_id"][r * n + k]
+            assert back["broken"][s * n + k] == bd["broken"][r * n + k]
+            assert back["sstress"][s * n + k] == bd["sstress"][r * n + k]
+    small = S.empty_bonds(n, 1)
+    assert lib.kid_restart_read_bonds(path.encode(), C.byref(_soa(b, n)), C.byref(_bond_soa(small, n))) == -4
+
+
+@pytest.mark.gpu
+def test_bonded_restart_round_trip(tmp_path):
+    """config-4 family: a bonded DEM conglomerate is written mid-run and restored; same bonds (as a set, with their state),
+    and the restored run goes on like the original"""
+    import parity as P
+    from icebergs_amd.framework import Icebergs
+    grid, p, b, bd = S.config_c4(nx=5, ny=7)
+    n = len(b["lon"])
+    a = Icebergs(grid, p, capacity=n)
+    a.upload_bergs(b)
+    a.upload_bonds(bd)
+    a.run(3)
+    a.write_restart(tmp_path)
+    assert os.path.exists(tmp_path / "bonds_iceberg.res.nc")
+    r = Icebergs(grid, p, capacity=n)
+    r.set_forcing(grid["forcing"])
+    r.read_restart(tmp_path)
+    ba, br = a.download_bergs(), r.download_bergs()
+    bda, bdr = a.download_bonds(bd["max_bonds"]), r.download_bonds(bd["max_bonds"])
+    assert np.array_equal(ba["id"], br["id"])        # rows of a bonded population keep their order
+    sa, sr = P.bond_set(ba, bda), P.bond_set(br, bdr)
+    assert set(sa) == set(sr) and len(sa) > 50
+    for key in sa:
+        ka, kr = sa[key], sr[key]
+        for name in ("tangd1", "tangd2", "nstress", "sstress", "rel_rotation"):
+            assert bda[name][ka] == bdr[name][kr], (key, name)
+        assert bda["broken"][ka] == bdr["broken"][kr]
+    for name in ("lon", "lat", "uvel", "vvel", "ang_vel", "rot", "axn_fast"):
+        assert np.array_equal(ba[name], br[name]), name
+    a.run(2)
+    r.run(2)
+    ba, br = a.download_bergs(), r.download_bergs()
+    for name in ("lon", "lat", "uvel", "vvel"):
+        assert np.allclose(ba[name], br[name], rtol=1e-6, atol=1e-9), (name, float(np.abs(ba[name] - br[name]).max()))
+    a.close()
+    r.close()

@@ -40,7 +40,7 @@ struct BergPtrs {
   int64_t *id;
   const double *orient;   // per-berg hexagon orientation from the bonds (IB:4004), or null: initial_orientation
 };
-struct Flags { int has_static, has_fl, store_env, footprint; };  // footprint: area/Uvel/Vvel_on_ocean are read by somebody
+struct Flags { int has_static, has_fl, store_env, footprint, no_diag; };   // no_diag: calculate_mass_on_ocean(with_diagnostics=.false.)  // footprint: area/Uvel/Vvel_on_ocean are read by somebody
 
 // -------------------------------------------------------------------------------------------------------
 // grid prepass kernels
@@ -276,7 +276,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
         spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg, fl.footprint != 0,
                     b.orient ? b.orient[kk] : p.initial_orientation);
-      berg_diagnostics(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
+      if (!fl.no_diag) berg_diagnostics(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
     seg_flush(seg, acc, ncell);
     KID_MARK("spread_done");
@@ -318,7 +318,8 @@ __global__ void set_grid_kernel(const DevGrid src, DevGrid *dst) { if (threadIdx
 // IB:6077-6150 sum_up_spread_fields + IB:3449-3488, per cell of the computational domain
 // -------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_params p, double *__restrict__ acc,
-                                                     double *__restrict__ out, const size_t ncell, double *__restrict__ totals) {
+                                                     double *__restrict__ out, const size_t ncell, double *__restrict__ totals,
+                                                     const double *__restrict__ spread_mass_old) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < KID_NSCALAR) {  // fold this step's increments into the running totals kept on `bergs` (IB:3130, 3295)
     totals[t] += acc[(size_t)KID_NACC * ncell + t];
@@ -362,6 +363,8 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
     if (sa == 0.0) ustar_h = 0.;
   }
   out[(size_t)KID_O_USTAR_ICEBERG * ncell + c] = ustar_h;
+  if (spread_mass_old)  // find_melt_using_spread_mass: the melt flux is what the gridded mass lost over the step, IB:3436-3445
+    acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = (a > 0.0) ? dmax((spread_mass_old[c] - sm) / p.dt, 0.0) : 0.0;
   if (p.apply_thickness_cutoff_to_gridded_melt && (p.melt_cutoff >= 0.) && (sa > 0.)) {  // IB:3477-3488 (comp. domain)
     const double ave_thickness = sm / (sa * p.rho_bergs);
     const double ave_draft = ave_thickness * (p.rho_bergs / RHO_SEAWATER);
@@ -369,6 +372,23 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
       acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = 0.0; acc[(size_t)KID_A_CALVING_HFLX * ncell + c] = 0.0;
     }
   }
+}
+
+// sum_up_spread_fields(.., 'mass') alone (IB:6126-6138) into a plane of its own: grd%spread_mass_old, IB:5495-5497
+__global__ void __launch_bounds__(256) mass_gather_kernel(const DevGrid g, const double *__restrict__ acc, double *__restrict__ plane, const size_t ncell) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nic = g.iec - g.isc + 1, njc = g.jec - g.jsc + 1;
+  if (t >= nic * njc) return;
+  const int i = g.isc + t % nic, j = g.jsc + t / nic;
+  const int c = g.idx(i, j), ni = g.ni;
+  const double a = g.geo[c].area, m = g.geo[c].msk;
+  const double *v = acc + (size_t)KID_A_MASS_ON_OCEAN * ncell;
+#define KID_V(di, dj, s) v[(size_t)((s) - 1) * ncell + (size_t)(c + (di) + (dj) * ni)]
+  double dmda = KID_V(0, 0, 5) + (((KID_V(-1, -1, 9) + KID_V(1, 1, 1)) + (KID_V(1, -1, 7) + KID_V(-1, 1, 3)))
+                                 + ((KID_V(-1, 0, 6) + KID_V(1, 0, 4)) + (KID_V(0, -1, 8) + KID_V(0, 1, 2))));
+#undef KID_V
+  if (a > 0) dmda = dmda / a * m;
+  plane[c] = dmda;
 }
 
 __global__ void __launch_bounds__(256) count_alive_kernel(const int32_t *alive, long long n, unsigned long long *out) {
@@ -523,7 +543,8 @@ struct kid_handle {
   hipGraphExec_t sub_graph_exec = nullptr;  // the captured sub-step loop of evolve_icebergs_mts
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
   bool use_graph = true;
-  Flags flags{0, 0, 1, 0};
+  Flags flags{0, 0, 1, 0, 0};
+  double *d_spread_mass_old = nullptr;   // grd%spread_mass_old (find_melt_using_spread_mass, IB:5495-5497)
   bool have_static = false, have_forcing = false, have_planes = false;  // have_planes: d_forcing holds all eleven planes
   double *d_calv_state = nullptr, *d_calv_scal = nullptr, *d_calv_part = nullptr; unsigned char *d_calv_flag = nullptr; int2 *d_calv_list = nullptr; double *calv_host = nullptr; kid_calving_params calv_params{};  // kid_calving (kid_calving.inc)
   bool calving_on = false, calving_first_call = true, rmean_init = false, rmean_hflx_init = false;
@@ -595,7 +616,10 @@ static int check_params(kid_handle *h, const kid_params *p) {
   // fills mass/area/Uvel/Vvel_on_ocean, but calculate_mass_on_ocean zeroes those planes again (IB:4984-4987) without
   // refilling them (IB:4997), and nothing reads them in between: the reference's spread_mass is identically zero in
   // this mode.  So the stage spreading is not launched and the spreading phase skips the berg (berg_kernel, PH_SPREAD).
-  if (p->find_melt_using_spread_mass) { h->err = "find_melt_using_spread_mass is not implemented"; return KID_EUNSUPPORTED; }
+  if (p->find_melt_using_spread_mass && (p->Iceberg_melt_without_decay || p->mts || p->interactive_icebergs_on || p->footloose)) {
+    h->err = "find_melt_using_spread_mass is implemented for the plain evolve loop only (no Iceberg_melt_without_decay, bonds, interactions or footloose)";
+    return KID_EUNSUPPORTED;
+  }
   if (p->footloose && p->displace_fl_bergs) { h->err = "footloose with displace_fl_bergs needs FMS's random stream: use displace_fl_bergs=F"; return KID_EUNSUPPORTED; }
   if (p->Runge_not_Verlet && p->footloose) { h->err = "Runge_not_Verlet must be false to use footloose (FW:1485-1490)"; return KID_EINVAL; }
   if (p->footloose && !p->use_operator_splitting) { h->err = "use_operator_splitting must be true to use footloose (FW:1476)"; return KID_EINVAL; }
@@ -719,6 +743,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_trc2) (void)hipFree(h->d_trc2);
   if (h->d_lane) (void)hipFree(h->d_lane);
   if (h->d_lane_alt) (void)hipFree(h->d_lane_alt);
+  if (h->d_spread_mass_old) (void)hipFree(h->d_spread_mass_old);
   if (h->evR) (void)hipEventDestroy(h->evR);
   if (h->evC) (void)hipEventDestroy(h->evC);
   if (h->evP) (void)hipEventDestroy(h->evP);
@@ -1232,7 +1257,7 @@ static int launch_berg(kid_handle *h) {
 static bool lanes_eligible(const kid_handle *h) {
   const kid_params &p = h->params;
   return h->side_mode == 2 && h->side_stream && p.old_interp_flds_order && !p.static_icebergs && !p.mts && !p.interactive_icebergs_on &&
-         !p.footloose && !(p.grounding_fraction > 0.) && h->n >= 4096;
+         !p.footloose && !(p.grounding_fraction > 0.) && !p.find_melt_using_spread_mass && h->n >= 4096;
 }
 static int launch_berg_lanes(kid_handle *h) {
   constexpr unsigned PH = PH_EVOLVE | PH_THERMO | PH_SPREAD;
@@ -1380,7 +1405,8 @@ static int launch_gather(kid_handle *h) {
   { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   const DevGrid g = dev_grid(h);
   const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell, h->d_totals);
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell, h->d_totals,
+                     (const double *)(h->params.find_melt_using_spread_mass ? h->d_spread_mass_old : nullptr));
   KID_HIP(h, hipGetLastError());
   return KID_OK;
 }
@@ -1430,6 +1456,24 @@ int kid_step_local(kid_handle *h) {
     rc = kid_footloose_calving(h);
     if (rc) return rc;
     return launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
+  }
+  if (p.find_melt_using_spread_mass) {
+    // IB:5490-5503: the gridded mass BEFORE the thermodynamics (calculate_mass_on_ocean without diagnostics, the 'mass'
+    // gather into grd%spread_mass_old, planes reset), then thermodynamics + create_gridded_icebergs_fields as usual; the
+    // gather replaces floating_melt by (spread_mass_old - spread_mass)/dt (IB:3436-3445)
+    if (!h->d_spread_mass_old) { KID_HIP(h, hipMalloc(&h->d_spread_mass_old, h->ncell * sizeof(double))); KID_HIP(h, hipMemsetAsync(h->d_spread_mass_old, 0, h->ncell * sizeof(double), h->stream)); }
+    if (!p.static_icebergs) { rc = p.old_interp_flds_order ? launch_berg<PH_EVOLVE>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h); if (rc) return rc; }
+    const size_t on_ocean = (size_t)KID_A_MASS_ON_OCEAN * h->ncell, on_bytes = 36 * h->ncell * sizeof(double);
+    KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
+    const Flags keep = h->flags;
+    h->flags.no_diag = 1; h->flags.footprint = 0;
+    rc = launch_berg<PH_SPREAD>(h);
+    h->flags = keep;
+    if (rc) return rc;
+    { const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
+      hipLaunchKernelGGL(mass_gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), (const double *)h->d_acc, h->d_spread_mass_old, h->ncell); }
+    KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
+    return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
   }
   if (p.old_interp_flds_order) {
     if (p.static_icebergs) rc = launch_berg<PH_THERMO | PH_SPREAD>(h);

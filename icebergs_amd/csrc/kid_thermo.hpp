@@ -312,7 +312,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   }
   unsigned nerr = (active && area == 0.) ? 1u : 0u;  // FATAL 'berg appears to have grounded!' IB:3207
   if (p.allow_bergs_to_roll && N_bonds == 0.) rolling(p, Tn, Wn, Ln);
-  if (p.Iceberg_melt_without_decay) {  // IB:3214-3257 (find_melt_using_spread_mass variant unsupported)
+  if (p.Iceberg_melt_without_decay) {  // IB:3214-3257 (with find_melt_using_spread_mass the reference also spreads the new masses here, IB:3225: refused at kid_create)
     Mnew = M;
     b.fl_k = fl_k;
   } else {

@@ -38,6 +38,8 @@ def needs_footprint_planes(params):
 
 def accumulator_views(acc_block, ncell, diag_mask=0, params=None):
     """(planes that must be reduced, scalar increments) as views of the contiguous accumulator block."""
+    if params is not None and params.find_melt_using_spread_mass:
+        raise NotImplementedError("find_melt_using_spread_mass needs grd%spread_mass_old summed over the ranks too: single-GPU only")
     diag_planes = sum(T.ENUMS[k] for k in (
         "KID_DIAG_MELT_BY_CLASS", "KID_DIAG_FL_PARENT_MELT", "KID_DIAG_FL_CHILD_MELT", "KID_DIAG_MELT_BUOY",
         "KID_DIAG_MELT_EROS", "KID_DIAG_MELT_CONV", "KID_DIAG_MELT_BUOY_FL", "KID_DIAG_MELT_EROS_FL",

@@ -1388,6 +1388,7 @@ static void sum_up_spread_field(const ko_grid *g, const double *acc, int base, i
 #undef V
 }
 /* calculate_mass_on_ocean (IB:4970-5011): the per-berg scatter half of create_gridded_icebergs_fields */
+static int g_mass_only = 0;   /* calculate_mass_on_ocean(with_diagnostics=.false.), IB:5490 */
 void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
   for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
@@ -1409,6 +1410,7 @@ void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_
       spread_mass(g, p, acc, bs, i, j, bs[KID_B_XI], bs[KID_B_YJ], bs[KID_B_MASS], bs[KID_B_MASS_OF_BITS], bs[KID_B_MASS_SCALING],
                   bs[KID_B_LENGTH] * bs[KID_B_WIDTH], bs[KID_B_THICKNESS], 1);
     g_orient_use = 0;
+    if (g_mass_only) continue;
     const size_t c = GIDX(g, i, j);
     const double ms = bs[KID_B_MASS_SCALING];
 #define ACC(F, v) acc[(size_t)(F) * ncell + c] = acc[(size_t)(F) * ncell + c] + (v)
@@ -1440,6 +1442,7 @@ void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_
 }
 /* the per-cell half: sum_up_spread_fields (IB:6077-6150) + IB:3449-3488.  In a particle-sharded run this is what
  * follows the all-reduce of the accumulators. */
+static const double *g_spread_mass_old = NULL;   /* grd%spread_mass_old while ko_run_step runs with find_melt_using_spread_mass */
 void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double *out) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
   const int dm = p->diag_mask;
@@ -1475,6 +1478,13 @@ void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double
       double ustar_h = dmax(p->ustar_icebergs_bg, ustar);
       if (o_area[c] == 0.0) ustar_h = 0.;
       o_us[c] = ustar_h;
+    }
+  }
+  if (g_spread_mass_old) {  /* find_melt_using_spread_mass, IB:3436-3445: spread_mass_tmp = spread_mass on the computational domain, 0 in the halo */
+    for (int j = g->d.jsd; j <= g->d.jed; ++j) for (int i = g->d.isd; i <= g->d.ied; ++i) {
+      size_t c = GIDX(g, i, j);
+      const int in_c = i >= g->d.isc && i <= g->d.iec && j >= g->d.jsc && j <= g->d.jec;
+      acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = (GS(g, KID_G_AREA, i, j) > 0.0) ? dmax((g_spread_mass_old[c] - (in_c ? o_mass[c] : 0.)) / p->dt, 0.0) : 0.0;
     }
   }
   if (p->apply_thickness_cutoff_to_gridded_melt) {
@@ -1515,8 +1525,18 @@ void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t
   if (!p->static_icebergs) ko_evolve_icebergs(g, p, b, scalars);
   if (p->footloose) ko_footloose_calving(g, p, b, capacity, acc, scalars);
   if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
+  double *spread_mass_old = NULL;
+  if (p->find_melt_using_spread_mass) {  /* IB:5490-5503 (the Iceberg_melt_without_decay variant, IB:3225/3411, is not restated) */
+    g_mass_only = 1; ko_calculate_mass_on_ocean(g, p, b, acc); g_mass_only = 0;
+    spread_mass_old = (double *)calloc(ncell, sizeof(double));
+    sum_up_spread_field(g, acc, KID_A_MASS_ON_OCEAN, 0, spread_mass_old);
+    for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
+  }
   ko_thermodynamics(g, p, b, acc, scalars);
+  g_spread_mass_old = spread_mass_old;   /* IB:3436-3445 happens inside create_gridded_icebergs_fields, before the cutoff of IB:3477 */
   ko_create_gridded_icebergs_fields(g, p, b, acc, out);
+  g_spread_mass_old = NULL;
+  free(spread_mass_old);
   int64_t alive = 0;
   for (int64_t k = 0; k < b->n; ++k) alive += berg_alive(b, k);
   scalars[KID_S_NBERGS_ALIVE] = (double)alive;

@@ -358,6 +358,27 @@ def test_time_average_weight(oracle, verlet):
     assert np.abs(got[1][T.ENUMS["KID_A_FLOATING_MELT"]]).max() > 0   # the melt fluxes are still there
 
 
+@pytest.mark.parametrize("variant", ["rk4", "verlet_new_order", "cutoff"])
+def test_find_melt_using_spread_mass(oracle, variant):
+    """find_melt_using_spread_mass=T (IB:5490-5503, 3436-3445): the melt flux handed to the ocean is the gridded mass the
+    step lost, max((spread_mass_old - spread_mass)/dt, 0), not the sum of the bergs' own melt terms"""
+    from icebergs_amd import types as T
+    grid, p, b = S.config_c2(n=4000, seed=33, continents=True)
+    S.set_diag_all(p)
+    p.find_melt_using_spread_mass = 1
+    if variant == "verlet_new_order":
+        p.Runge_not_Verlet, p.old_interp_flds_order = 0, 0
+    if variant == "cutoff":
+        p.apply_thickness_cutoff_to_gridded_melt, p.melt_cutoff = 1, 3800.0   # cells whose mean draught exceeds 200 m are cut
+    ref, got = _both(grid, p, b, 6, "fused")
+    P.compare(ref, got, "find_melt/" + variant, params=p)
+    q = S.params_copy(p)
+    q.find_melt_using_spread_mass = 0
+    plain = P.run_oracle(grid, q, b, 6)
+    k = T.ENUMS["KID_A_FLOATING_MELT"]
+    assert np.abs(ref[1][k]).max() > 0 and not np.allclose(ref[1][k], plain[1][k], rtol=1e-3)   # it IS a different flux
+
+
 def test_slow_lane_with_collective_matches_plain(oracle):
     """the N>1 code path of the slow-lane schedule (RCCL all-reduce + gather on a third stream), rehearsed with one
     rank: must give what the serial single-stream sequence gives"""

@@ -27,6 +27,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ALGO_BYTES_PER_BERG_STEP = 256.0  # SURVEY.md 8d (config 2): 129 B read + 128 B written of per-berg SoA state
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6           # MI355X vector fp64 peak
+# hot build, per berg-step: 637 FMA (x2) + 1066 ADD + ~1000 MUL fp64 lane-ops (SQ_INSTS_VALU_FMA_F64 / ADD_F64 x 64 lanes / 1e6 bergs)
+FP64_FLOP_PER_BERG_STEP = 3300.0
 
 
 def cpu_baseline(nbergs, nsteps):
@@ -176,7 +179,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "berg_kernel<true, true, 14u, true> (RK4, old interp order, evolve|thermo|spread, hot build)",
                          "kernel_ms_avg": kern_ms, "kernel_launches": launches, "bergs_per_launch": bergs_per_launch,
-                         "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
+                         "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP,
+                         # SURVEY 8d asks for GFLOP/s beside GB/s: the kernel sits at the ridge (AI ~ 12 flop/B).  Flops per berg-step
+                         # from the committed PMC pass (profiles/r01_pmc_valu.txt: 2 x FMA_F64 + ADD_F64 + as many MUL_F64 as ADD, per lane)
+                         "fp64_flop_per_berg_step": FP64_FLOP_PER_BERG_STEP,
+                         "fp64_achieved_tflops": FP64_FLOP_PER_BERG_STEP * bergs_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                         "fp64_peak_tflops": FP64_PEAK_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_bergs, args.cpu_steps)

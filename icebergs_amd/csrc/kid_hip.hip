@@ -32,7 +32,7 @@ using namespace kid;
 
 namespace {
 
-enum : unsigned { PH_INTERP = 1u, PH_EVOLVE = 2u, PH_THERMO = 4u, PH_SPREAD = 8u };
+enum : unsigned { PH_INTERP = 1u, PH_EVOLVE = 2u, PH_THERMO = 4u, PH_SPREAD = 8u, PH_FL = 16u };   // PH_FL: footloose_calving between evolve and thermodynamics
 
 struct BergPtrs {
   double *f[KID_NB_F64];
@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec
 #ifndef KID_GENERAL_WAVES_PER_EU
 #define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
 #endif
-struct Redo { int *list; int *count; long long k0, klen; int *lane; int step; };   // k0, klen: the rows the hot build covers in this launch
+struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;    // k0, klen: the rows the hot build covers in this launch
+              int *fl_cursor; int32_t *fl_counter; long long fl_capacity; int fl_iNg; };   // PH_FL: where footloose children go (FlChildCtx)
 // lane/step ("slow lane" schedule, launch_berg_lanes): lane[k] >= step means berg k is owned by general-build launches that
 // may still be running on the side stream; the hot build of this step leaves it alone.  A berg the hot build hands over
 // at step s gets lane = s + 1: the general build does its steps s and s + 1, the hot build has it back at s + 2.
@@ -233,6 +234,17 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   KID_PHASE_FENCE();
   KID_MARK("evolve_done");
 
+  if (PH & PH_FL) {  // footloose_calving (IB:5453, 2503-2734) on the berg's own rows between its evolve and its thermodynamics:
+    // per berg the reference's order is evolve -> footloose -> thermodynamics too, and nothing of another berg is read.
+    // The state goes through memory (this lane has just stored it); children are appended behind the population and get
+    // their thermodynamics + spreading from a second launch over the new rows (kid_step_local).
+    if (was_alive && !skipped && t.alive) {
+      const FlChildCtx cx{redo.fl_cursor, redo.fl_counter, n, redo.fl_capacity, redo.fl_iNg};
+      footloose_one(g, p, b, cx, kk, acc, ncell, scal);
+      t.M = b.f[KID_B_MASS][kk]; t.T = b.f[KID_B_THICKNESS][kk]; t.W = b.f[KID_B_WIDTH][kk]; t.L = b.f[KID_B_LENGTH][kk];
+    }
+  }
+
   if (PH & (PH_THERMO | PH_SPREAD)) {
     const bool active = t.alive && !skipped;
     if (!FAST) seg = make_runs(active ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);  // cells may have changed
@@ -247,6 +259,9 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     t.start_mass = (p.diag_mask & KID_DIAG_MELT_BY_CLASS) ? b.f[KID_B_START_MASS][kk] : 0.;
     t.start_year = 0; t.start_day = 0.;
     if (PH & PH_THERMO) {
+      if (!OLD_ORDER && (PH & PH_EVOLVE) && (PH & PH_INTERP)) {  // fused step: interp_gridded_fields_to_bergs again at the new position, IB:5473
+        if (active) { interp_flds(p, cellv, d.xi, d.yj, e); env_dirty = true; }
+      }
       if (OLD_ORDER || (!p.mts && !p.dem && halo)) {  // IB:2890-2894 (od is not passed there)
         const double od_keep = e.od;
         if (active) { interp_flds(p, cellv, d.xi, d.yj, e); env_dirty = true; }
@@ -1194,9 +1209,9 @@ int kid_zero_accumulators(kid_handle *h) {
 
 static int refresh_tables(kid_handle *h);
 template <unsigned PH>
-static int launch_berg(kid_handle *h) {
+static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_len = -1) {   // range: the rows to step (default all)
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
-  if (h->n == 0) return KID_OK;
+  if (h->n == 0 || range_len == 0) return KID_OK;
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 { int rc_t = lanes_drain(h); if (rc_t) return rc_t; }
@@ -1210,13 +1225,14 @@ static int launch_berg(kid_handle *h) {
   // Pipelined (a side stream is set): two halves; the general build of a half runs on the side stream while the main
   // stream is already in the hot build of the other half (or of the next step): the ~85 us single-wave latency of the
   // general build leaves the critical path.  Events order a half's hot build behind its own previous general build.
-  const int nparts = (h->pipelined && !h->params.mts && !h->params.footloose && h->n >= 4096) ? 2 : 1;
+  const int nparts = (h->pipelined && !h->params.mts && !h->params.footloose && h->n >= 4096 && range_len < 0) ? 2 : 1;
   const long long half = ((h->n / 2 + 255) / 256) * 256;
   for (int part = 0; part < nparts; ++part) {
-    const long long k0 = (nparts == 1) ? 0 : (part == 0 ? 0 : half);
-    const long long klen = (nparts == 1) ? h->n : (part == 0 ? half : h->n - half);
+    const long long k0 = (nparts == 1) ? range_k0 : (part == 0 ? 0 : half);
+    const long long klen = (nparts == 1) ? (range_len < 0 ? h->n : range_len) : (part == 0 ? half : h->n - half);
     const unsigned nbp = (unsigned)((klen + 255) / 256);
-    const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen, nullptr, 0};
+    const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen, nullptr, 0,
+                    h->d_fl_cursor, h->d_iceberg_counter, (long long)h->capacity, h->gd.iec - h->gd.isc + 1};
     hipStream_t gs = (nparts == 2) ? h->side_stream : h->stream;
     if (h->evG_live[part]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[part], 0));
     if (nparts == 1 && h->evG_live[1]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[1], 0));
@@ -1450,7 +1466,27 @@ int kid_step_local(kid_handle *h) {
     if (rc) return rc;
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
   }
-  if (p.footloose) {  // calving sits between evolve and thermodynamics (IB:5453) and appends bergs: three launches
+  if (p.footloose && !p.static_icebergs && getenv("KID_FL_UNFUSED") == nullptr) {
+    // calving sits between evolve and thermodynamics (IB:5453): fused into the per-berg launch (PH_FL), one pass over the
+    // SoA instead of three (320 B per berg-step instead of 530).  The children it appends are new rows; they
+    // owe this step's thermodynamics and spreading, which a second, short launch over those rows delivers.
+    h->flags.has_fl = 1;
+    KID_HIP(h, hipMemsetAsync(h->d_fl_cursor, 0, sizeof(int), h->stream));
+    const long long n_old = h->n;
+    rc = p.old_interp_flds_order ? launch_berg<PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD>(h);
+    if (rc) return rc;
+    int appended = 0;  // the population grew: the host needs the new size before the next launch
+    KID_HIP(h, hipMemcpyAsync(&appended, h->d_fl_cursor, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    KID_HIP(h, hipStreamSynchronize(h->stream));
+    if (appended > h->capacity - n_old) {
+      h->n = h->capacity;
+      h->err = "footloose calving ran out of capacity: create the handle with room for child bergs";
+      return KID_ECAPACITY;
+    }
+    h->n = n_old + appended;
+    return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h, n_old, appended) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h, n_old, appended);
+  }
+  if (p.footloose) {  // phase by phase (KID_FL_UNFUSED, static bergs): three launches
     rc = launch_berg<PH_INTERP | PH_EVOLVE>(h);
     if (rc) return rc;
     rc = kid_footloose_calving(h);

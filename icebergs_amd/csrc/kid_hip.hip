@@ -1516,7 +1516,9 @@ int kid_step_local(kid_handle *h) {
     else if (lanes_eligible(h)) rc = launch_berg_lanes(h);
     else rc = launch_berg<PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
   } else {
-    // IB:5423: interpolate, evolve; IB:5473: interpolate again at the new position, then thermodynamics
+    // IB:5423: interpolate, evolve; IB:5473: interpolate again at the new position, then thermodynamics.  Per berg that
+    // is one chain, so one launch (the second interpolation sits between the phases inside berg_kernel)
+    if (!p.static_icebergs && getenv("KID_NEW_ORDER_UNFUSED") == nullptr) return launch_berg<PH_INTERP | PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
     rc = p.static_icebergs ? launch_berg<PH_INTERP>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h);
     if (rc) return rc;
     rc = launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);

@@ -55,6 +55,20 @@ def test_c1_verlet_new_interp_order(oracle):
         P.compare(ref, got, "C1/verlet-neworder/" + mode, params=p)
 
 
+@pytest.mark.parametrize("verlet", [False, True])
+def test_c2_new_interp_order_fused(oracle, verlet):
+    """.not.old_interp_flds_order at config-2 size with coasts: interpolate, evolve, interpolate again, melt and spread as
+    ONE launch per step (the second interpolation sits between the phases of berg_kernel), against the oracle's four
+    separate sweeps"""
+    grid, p, b = S.config_c2(n=30000, seed=41, continents=True)
+    S.set_diag_all(p)
+    p.old_interp_flds_order = 0
+    if verlet:
+        p.Runge_not_Verlet, p.use_new_predictive_corrective = 0, 1
+    ref, got = _both(grid, p, b, 12, "fused")
+    P.compare(ref, got, "C2/new-order/verlet=%s" % verlet, params=p)
+
+
 @pytest.mark.parametrize("continents", [False, True])
 def test_c2_latlon(oracle, continents):
     """BASELINE config 2 at an oracle-sized population: lat-lon 360x200 (calc_xiyj path), RK4, melt,

@@ -554,6 +554,7 @@ struct kid_handle {
   MtsDev mts{}; MtsDev *d_mts = nullptr;
   int mb = 0; bool mts_ready = false, mts_dirty = true, have_bonds = false, visited = false;
   unsigned long long *d_key64[2] = {nullptr, nullptr}; int *d_rows[2] = {nullptr, nullptr};
+  int *d_static_rows = nullptr; long long static_rows_n = -1, static_rows_cap = 0;   // rows ordered by the five static `inorder` keys (mts_build_order)
   void *d_mts_tmp = nullptr; size_t mts_tmp_bytes = 0;
   hipGraphExec_t sub_graph_exec = nullptr;  // the captured sub-step loop of evolve_icebergs_mts
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
@@ -945,6 +946,7 @@ int kid_upload_bergs(kid_handle *h, const kid_berg_soa *host) {
   if (host->n > h->capacity) { h->err = "more bergs than capacity"; return KID_ECAPACITY; }
   KID_HIP(h, hipSetDevice(h->device));
   { const int rc_j = lanes_drain(h); if (rc_j) return rc_j; }
+  h->static_rows_n = -1;   // the cached order by the static `inorder` keys belongs to the previous population
   const size_t n = (size_t)host->n;
   bool any_static = false, any_fl = false;
   for (int f = 0; f < KID_NB_F64; ++f) {

@@ -560,6 +560,9 @@ struct kid_handle {
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
   bool use_graph = true;
   Flags flags{0, 0, 1, 0, 0};
+  // trajectories (kid_traj.inc): one buffer per sampled field, grown on demand
+  bool traj_on = false; kid_traj_params traj_params{}; double *d_traj_f[64] = {}; double *d_traj_day = nullptr; int64_t *d_traj_id = nullptr;
+  int32_t *d_traj_year = nullptr, *d_traj_nbonds = nullptr; unsigned long long *d_traj_cursor = nullptr; long long traj_capacity = 0, traj_count_bound = 0; int traj_nf = 0;
   double *d_spread_mass_old = nullptr;   // grd%spread_mass_old (find_melt_using_spread_mass, IB:5495-5497)
   bool have_static = false, have_forcing = false, have_planes = false;  // have_planes: d_forcing holds all eleven planes
   double *d_calv_state = nullptr, *d_calv_scal = nullptr, *d_calv_part = nullptr; unsigned char *d_calv_flag = nullptr; int2 *d_calv_list = nullptr; double *calv_host = nullptr; kid_calving_params calv_params{};  // kid_calving (kid_calving.inc)
@@ -760,6 +763,12 @@ int kid_destroy(kid_handle *h) {
   if (h->d_lane) (void)hipFree(h->d_lane);
   if (h->d_lane_alt) (void)hipFree(h->d_lane_alt);
   if (h->d_spread_mass_old) (void)hipFree(h->d_spread_mass_old);
+  for (auto &q : h->d_traj_f) if (q) (void)hipFree(q);
+  if (h->d_traj_day) (void)hipFree(h->d_traj_day);
+  if (h->d_traj_id) (void)hipFree(h->d_traj_id);
+  if (h->d_traj_year) (void)hipFree(h->d_traj_year);
+  if (h->d_traj_nbonds) (void)hipFree(h->d_traj_nbonds);
+  if (h->d_traj_cursor) (void)hipFree(h->d_traj_cursor);
   if (h->evR) (void)hipEventDestroy(h->evR);
   if (h->evC) (void)hipEventDestroy(h->evC);
   if (h->evP) (void)hipEventDestroy(h->evP);
@@ -1617,3 +1626,4 @@ int kid_profile_get(kid_handle *h, double *berg_ms, int64_t *launches, double *a
 }  // extern "C"
 
 #include "kid_restart.inc"
+#include "kid_traj.inc"

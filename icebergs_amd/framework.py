@@ -126,6 +126,21 @@ class Icebergs:
         self._check(self.lib.kid_get_forcing(self.h, arr), "kid_get_forcing")
         return out
 
+    # ---- trajectories (record_posn FW:5328-5498, write_trajectory IO2:1631-2103) ----
+    def set_traj_params(self, tp):
+        self._check(self.lib.kid_set_traj_params(self.h, C.byref(tp)), "kid_set_traj_params")
+
+    def record_posn(self):
+        self._check(self.lib.kid_record_posn(self.h), "kid_record_posn")
+
+    def num_traj_records(self):
+        n = C.c_int64()
+        self._check(self.lib.kid_num_traj_records(self.h, C.byref(n)), "kid_num_traj_records")
+        return n.value
+
+    def write_trajectories(self, path):
+        self._check(self.lib.kid_write_trajectories(self.h, str(path).encode()), "kid_write_trajectories")
+
     # ---- restart files (icebergs_fms2io.F90:124-631, 663-1049) ----
     def write_restart(self, directory):
         self._check(self.lib.kid_write_restart(self.h, str(directory).encode()), "kid_write_restart")

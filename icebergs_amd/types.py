@@ -84,6 +84,10 @@ class CalvingParams(C.Structure):
     _fields_ = _parse_struct(_src, "kid_calving_params", ENUMS)
 
 
+class TrajParams(C.Structure):
+    _fields_ = _parse_struct(_src, "kid_traj_params", ENUMS)
+
+
 class CalvingIn(C.Structure):
     _fields_ = _parse_struct(_src, "kid_calving_in", ENUMS)
 

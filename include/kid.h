@@ -151,6 +151,16 @@ int kid_restart_read_bonds(const char *path, const kid_berg_soa *bergs, kid_bond
 int kid_write_restart(kid_handle *h, const char *dir);
 int kid_read_restart(kid_handle *h, const char *dir);
 
+/* ---- trajectories: record_posn (FW:5328-5498) as a device pass that appends one record per selected berg
+ * to buffers in HBM, and iceberg_trajectories.nc (icebergs_fms2io.F90:1631-2103) written from them: dimension "i", lon,
+ * lat, year, day, id_cnt, id_ij, then the save_fl_traj group, then the long group unless save_short_traj (same names,
+ * types and attributes).  kid_write_trajectories appends to an existing file, like the reference, and empties the buffers.
+ * Bond trajectories (save_bond_traj) are not recorded. */
+int kid_set_traj_params(kid_handle *h, const kid_traj_params *tp);
+int kid_record_posn(kid_handle *h);
+int kid_num_traj_records(kid_handle *h, int64_t *n);
+int kid_write_trajectories(kid_handle *h, const char *path);
+
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */
 int kid_step_prepare(kid_handle *h, const double *const device_fields[KID_NFORCING]);

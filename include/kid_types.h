@@ -84,6 +84,21 @@ typedef struct kid_calving_in {
   const double *calving_hflx;   /* (isc:iec, jsc:jec), W/m2,    IB:5080 */
   int32_t on_device, pad;       /* pointers are device addresses */
 } kid_calving_in;
+/* ---- trajectory sampling: which bergs record_posn samples and what iceberg_trajectories.nc holds
+ * (FW:5328-5498, icebergs_fms2io.F90:1631-2103); namelist values ---- */
+typedef struct kid_traj_params {
+  double traj_area_thres;                        /* km^2, FW:687 */
+  double traj_area_thres_sntbc;                  /* km^2, FW:688 */
+  double traj_area_thres_fl;                     /* km^2, FW:689 */
+  double save_all_traj_year;                     /* FW:763 */
+  double save_traj_by_class_start_mass_thres_s;  /* kg, FW:5375 */
+  double save_traj_by_class_start_mass_thres_n;  /* kg, FW:5377 */
+  int32_t save_short_traj;                       /* FW:759 */
+  int32_t save_fl_traj;                          /* FW:762 */
+  int32_t save_nonfl_traj_by_class;              /* FW:5371 */
+  int32_t pad;
+} kid_traj_params;
+
 /* what one kid_calving call adds to the budget scalars of type icebergs (increments; the first two `stored` entries
  * are the values the first call prints, zero afterwards) */
 enum {

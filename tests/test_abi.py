@@ -64,5 +64,5 @@ def test_structs_have_no_implicit_padding():
     """Fortran stream I/O and bind(C) derived types move components one by one: every pad must be spelled out"""
     import ctypes
     from icebergs_amd import types as T
-    for cls in (T.Params, T.GridDesc, T.BergSoA, T.BondSoA, T.ForcingIn, T.CalvingParams, T.CalvingIn):
+    for cls in (T.Params, T.GridDesc, T.BergSoA, T.BondSoA, T.ForcingIn, T.CalvingParams, T.CalvingIn, T.TrajParams):
         assert ctypes.sizeof(cls) == sum(ctypes.sizeof(t) for _, t in cls._fields_), cls.__name__

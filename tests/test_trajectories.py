@@ -1,0 +1,104 @@
+"""Trajectory sampling from the structure of arrays (record_posn FW:5328-5498, write_trajectory
+IO2:1631-2103): which bergs are sampled, what a record holds, and the file as an independent reader sees it."""
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+from icebergs_amd import synthetic as S
+from icebergs_amd import types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _selected(b, p, tp):
+    """the selection of record_posn (FW:5370-5388) restated with numpy on a downloaded population"""
+    area = b["mass"] / (p.rho_bergs * b["thickness"])
+    by_class = np.zeros(len(area), dtype=bool)
+    if tp.save_nonfl_traj_by_class:
+        thres = np.where(b["lat"] < 0, tp.save_traj_by_class_start_mass_thres_s, tp.save_traj_by_class_start_mass_thres_n)
+        by_class = (b["fl_k"] >= 0) & (area > tp.traj_area_thres_sntbc * 1e6) & (b["start_mass"] >= thres)
+    fl = (b["fl_k"] < 0) & (area > tp.traj_area_thres_fl * 1e6)
+    return (b["alive"] != 0) & ((p.current_year > tp.save_all_traj_year) | by_class | (area >= tp.traj_area_thres * 1e6) | fl)
+
+
+def _tp(**kw):
+    tp = T.TrajParams()
+    tp.traj_area_thres, tp.traj_area_thres_sntbc, tp.traj_area_thres_fl = 0.0, 0.0, 1.0e9    # namelist defaults, FW:687-689
+    tp.save_all_traj_year = 1.0e30
+    tp.save_short_traj, tp.save_fl_traj, tp.save_nonfl_traj_by_class = 1, 1, 0               # FW:759, 762
+    for k, v in kw.items():
+        setattr(tp, k, v)
+    return tp
+
+
+def test_sampling_and_file(tmp_path):
+    from icebergs_amd.framework import Icebergs
+    grid, p, b = S.config_c2(n=5000, seed=51, continents=True)
+    p.current_year, p.current_yearday = 4, 10.0
+    tp = _tp(traj_area_thres=0.05, save_short_traj=0)      # bergs of at least 0.05 km^2; long records
+    ib = Icebergs(grid, p, capacity=5000)
+    ib.set_forcing(grid["forcing"])
+    ib.upload_bergs(b)
+    ib.set_traj_params(tp)
+    ib.set_store_environment(True)
+    expect = []
+    for s in range(3):                                     # sample, step, sample, ... (IB:5516 after the step; here before, same thing)
+        p.current_yearday = 10.0 + s
+        ib.set_params(p)
+        ib.record_posn()
+        cur = ib.download_bergs()
+        sel = _selected(cur, p, tp)
+        expect.append((cur, sel, p.current_yearday))
+        ib.run(2)
+    ntot = sum(int(sel.sum()) for _, sel, _ in expect)
+    assert 0 < int(expect[0][1].sum()) < 5000 and ib.num_traj_records() == ntot
+    path = tmp_path / "iceberg_trajectories.nc"
+    ib.write_trajectories(path)
+    assert ib.num_traj_records() == 0
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        names = list(f.variables)
+        assert names[:12] == ["lon", "lat", "year", "day", "id_cnt", "id_ij", "mass", "start_mass", "thickness", "mass_of_bits", "uvel", "vvel"]
+        assert names[12:] == ["uvel_prev", "vvel_prev", "uo", "vo", "ui", "vi", "ua", "va", "heat_density", "width", "length", "ssh_x", "ssh_y",
+                              "sst", "sss", "cn", "hi", "axn", "ayn", "bxn", "byn", "halo_berg", "od"]
+        assert f.variables["year"].typecode() == "i" and f.variables["id_ij"].typecode() == "i" and f.variables["day"].typecode() == "d"
+        assert f.variables["uvel"].long_name == b"zonal spped" and f.variables["od"].long_name == b"ocean_depth"      # sic, IO2:1918, 1977
+        assert not hasattr(f.variables["uvel_prev"], "long_name")
+        assert f.variables["lon"].shape == (ntot,)
+        ident = (f.variables["id_cnt"][:].astype(np.int64) << 32) + f.variables["id_ij"][:].astype(np.int64)
+        day = f.variables["day"][:]
+        for cur, sel, d in expect:
+            rows = np.nonzero(day == d)[0]
+            assert len(rows) == int(sel.sum()) and np.all(f.variables["year"][:][rows] == 4)
+            o_file, o_ref = np.argsort(ident[rows]), np.argsort(cur["id"][sel])
+            assert np.array_equal(ident[rows][o_file], cur["id"][sel][o_ref])
+            for name in ("lon", "lat", "mass", "thickness", "uvel", "vvel", "uo", "sst", "width", "axn", "od", "start_mass"):
+                assert np.array_equal(f.variables[name][:][rows][o_file], cur[name][sel][o_ref]), name
+    # the next batch extends the file
+    p.current_yearday = 20.0
+    ib.set_params(p)
+    ib.record_posn()
+    more = ib.num_traj_records()
+    ib.write_trajectories(path)
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        assert f.variables["lon"].shape == (ntot + more,) and np.all(f.variables["day"][:][ntot:] == 20.0)
+    ib.close()
+
+
+def test_short_records_and_save_all_year(tmp_path):
+    from icebergs_amd.framework import Icebergs
+    grid, p, b = S.config_c2(n=2000, seed=52)
+    p.current_year = 9
+    ib = Icebergs(grid, p, capacity=2000)
+    ib.set_forcing(grid["forcing"])
+    ib.upload_bergs(b)
+    ib.set_traj_params(_tp(traj_area_thres=1.0e9, save_fl_traj=0))        # nothing is big enough ...
+    ib.record_posn()
+    assert ib.num_traj_records() == 0
+    ib.set_traj_params(_tp(traj_area_thres=1.0e9, save_fl_traj=0, save_all_traj_year=8.0))   # ... but after year 8 everything is saved
+    ib.record_posn()
+    assert ib.num_traj_records() == 2000
+    path = tmp_path / "short.nc"
+    ib.write_trajectories(path)
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        assert list(f.variables) == ["lon", "lat", "year", "day", "id_cnt", "id_ij"] and f.variables["lon"].shape == (2000,)
+    ib.close()

@@ -1283,11 +1283,12 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
 // at launch; the caller alternates two blocks and launches the gather on the side stream (PipelinedStepper).
 static bool lanes_eligible(const kid_handle *h) {
   const kid_params &p = h->params;
-  return h->side_mode == 2 && h->side_stream && p.old_interp_flds_order && !p.static_icebergs && !p.mts && !p.interactive_icebergs_on &&
+  return h->side_mode == 2 && h->side_stream && !p.static_icebergs && !p.mts && !p.interactive_icebergs_on &&
          !p.footloose && !(p.grounding_fraction > 0.) && !p.find_melt_using_spread_mass && h->n >= 4096;
 }
+template <bool OLDV>
 static int launch_berg_lanes(kid_handle *h) {
-  constexpr unsigned PH = PH_EVOLVE | PH_THERMO | PH_SPREAD;
+  constexpr unsigned PH = OLDV ? (PH_EVOLVE | PH_THERMO | PH_SPREAD) : (PH_INTERP | PH_EVOLVE | PH_THERMO | PH_SPREAD);
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
   { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }
   const bool rk = h->params.Runge_not_Verlet != 0;
@@ -1295,7 +1296,7 @@ static int launch_berg_lanes(kid_handle *h) {
   hipStream_t M = h->stream, S = h->side_stream;
   const int s = h->lane_step, par = s & 1;
   h->tail_valid = false;
-  if (h->flags.store_env) h->env_ever_stored = true;
+  if (h->flags.store_env || !OLDV) h->env_ever_stored = true;
   h->lanes_active = true;
   for (int q = 0; q < 2; ++q) if (h->evG_live[q] && h->pipelined) { KID_HIP(h, hipStreamWaitEvent(M, h->evG[q], 0)); h->evG_live[q] = false; }
   if (!h->redo_prezeroed) {  // no prepass: zero this step's counter here (it was last read by the previous carry-over launch)
@@ -1316,11 +1317,11 @@ static int launch_berg_lanes(kid_handle *h) {
 #define KID_LAUNCH_LANES(RKV)                                                                                                   \
   do {                                                                                                                          \
     if (h->carry_valid)                                                                                                         \
-      hipLaunchKernelGGL((berg_kernel<RKV, true, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, carry); \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, carry); \
     /* recorded even without a carry-over launch: everything enqueued on the side stream so far (the gather of the step  \
        before last included) is complete once the next prepass has waited for it */                                          \
     (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
-    hipLaunchKernelGGL((berg_kernel<RKV, true, PH, true>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(evF, M);                                                                                               \
     if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }                                                    \
     if (rebin_now) {                                                                                                            \
@@ -1332,7 +1333,7 @@ static int launch_berg_lanes(kid_handle *h) {
       if (!h->evR) (void)hipEventCreateWithFlags(&h->evR, hipEventDisableTiming);                                               \
       (void)hipEventRecord(h->evR, M); (void)hipStreamWaitEvent(S, h->evR, 0);                                                  \
     } else (void)hipStreamWaitEvent(S, evF, 0);                                                                                 \
-    hipLaunchKernelGGL((berg_kernel<RKV, true, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(h->evG[0], S); h->evG_live[0] = true;                                                                  \
   } while (0)
   const bool rebin_now = h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval && !h->have_bonds && getenv("KID_STABLE_RESORT") == nullptr;
@@ -1524,11 +1525,12 @@ int kid_step_local(kid_handle *h) {
   }
   if (p.old_interp_flds_order) {
     if (p.static_icebergs) rc = launch_berg<PH_THERMO | PH_SPREAD>(h);
-    else if (lanes_eligible(h)) rc = launch_berg_lanes(h);
+    else if (lanes_eligible(h)) rc = launch_berg_lanes<true>(h);
     else rc = launch_berg<PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
   } else {
     // IB:5423: interpolate, evolve; IB:5473: interpolate again at the new position, then thermodynamics.  Per berg that
     // is one chain, so one launch (the second interpolation sits between the phases inside berg_kernel)
+    if (lanes_eligible(h)) return launch_berg_lanes<false>(h);
     if (!p.static_icebergs && getenv("KID_NEW_ORDER_UNFUSED") == nullptr) return launch_berg<PH_INTERP | PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
     rc = p.static_icebergs ? launch_berg<PH_INTERP>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h);
     if (rc) return rc;

@@ -141,7 +141,7 @@ class PipelinedStepper:
     @staticmethod
     def _slow_lane_eligible(ib, p):
         """mirror of lanes_eligible() in csrc/kid_hip.hip: the fused step without footloose, bonds or interactions"""
-        return bool(p.old_interp_flds_order and not p.static_icebergs and not p.mts and not p.interactive_icebergs_on
+        return bool(not p.static_icebergs and not p.mts and not p.interactive_icebergs_on
                     and not p.footloose and not (p.grounding_fraction > 0.0) and ib.num_bergs()[0] >= 4096)
 
     def step(self):

@@ -65,8 +65,8 @@ int kid_set_stream(kid_handle *h, void *hip_stream);
  * general-build launches on `side_stream` for steps s and s+1 (under the hot builds of s+1 and s+2) and returns to the
  * hot build at s+2, so the general build's latency never sits between two hot builds.  The caller alternates two
  * accumulator blocks (kid_bind_accum_buffer) and launches the gather on the side stream; the per-cell forcing records
- * are double-buffered inside.  Applies to the fused RK4/Verlet step without footloose, bonds or interactions and falls
- * back to the plain schedule otherwise. */
+ * are double-buffered inside.  Applies to the fused RK4/Verlet step (either interpolation order) without footloose, bonds
+ * or interactions and falls back to the plain schedule otherwise. */
 int kid_set_side_stream(kid_handle *h, void *side_stream, int enable);
 int kid_sync(kid_handle *h);
 const char *kid_last_error(const kid_handle *h);

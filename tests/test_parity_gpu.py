@@ -301,7 +301,7 @@ def test_c4_mts_dem(oracle, case):
         assert (refbd["broken"] != 0).sum() > 0  # the case does fracture
 
 
-@pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag", "slow_lane_verlet"])
+@pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag", "slow_lane_verlet", "slow_lane_new_order"])
 def test_pipelined_stepper_matches_plain(oracle, split_general):
     """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)
     must give what the plain sequence gives; run here on one GPU, with and without a (world-size-1) RCCL all-reduce."""
@@ -315,6 +315,8 @@ def test_pipelined_stepper_matches_plain(oracle, split_general):
         S.set_diag_all(p)
     if split_general == "slow_lane_verlet":
         p.Runge_not_Verlet = 0
+    if split_general == "slow_lane_new_order":   # .not.old_interp_flds_order: the stored environment travels with the berg
+        p.Runge_not_Verlet, p.old_interp_flds_order, p.use_new_predictive_corrective = 0, 0, 1
     nsteps = 37
     dev = torch.device("cuda", 0)
     forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]

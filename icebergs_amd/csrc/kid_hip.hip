@@ -824,6 +824,9 @@ static int lanes_drain(kid_handle *h) {
   const int rc = join_side(h);
   if (rc || !h->lanes_active) return rc;
   KID_HIP(h, hipMemsetAsync(h->d_lane, 0, (size_t)h->capacity * sizeof(int), h->stream));
+  // the other buffer of the in-step re-binning too: its rows beyond the population would come back with stamps of a
+  // step count that starts over below
+  if (h->d_lane_alt) KID_HIP(h, hipMemsetAsync(h->d_lane_alt, 0, (size_t)h->capacity * sizeof(int), h->stream));
   h->lanes_active = false; h->carry_valid = false; h->lane_step = 1;
   return KID_OK;
 }
@@ -1178,7 +1181,7 @@ static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_
   for (int f = 0; f < KID_NB_I32; ++f) { t.src[t.n8 + t.n4] = h->bp.i[f]; t.dst[t.n8 + t.n4] = h->bp_alt.i[f]; ++t.n4; }
   if (with_lane) {
     if (h->stable_resort) { h->err = "KID_STABLE_RESORT has no inverse permutation for the slow-lane re-binning"; return KID_EUNSUPPORTED; }
-    if (!h->d_lane_alt) KID_HIP(h, hipMalloc(&h->d_lane_alt, (size_t)h->capacity * sizeof(int)));
+    if (!h->d_lane_alt) { KID_HIP(h, hipMalloc(&h->d_lane_alt, (size_t)h->capacity * sizeof(int))); KID_HIP(h, hipMemsetAsync(h->d_lane_alt, 0, (size_t)h->capacity * sizeof(int), h->stream)); }
     t.src[t.n8 + t.n4] = h->d_lane; t.dst[t.n8 + t.n4] = h->d_lane_alt; ++t.n4;
   }
   hipLaunchKernelGGL(permute_all_kernel, dim3(nb), dim3(256), 0, h->stream, t, perm, n);

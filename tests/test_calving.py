@@ -225,3 +225,43 @@ def test_calving_capacity_and_device_inputs():
     with pytest.raises(L.KidError, match="rc=-4"):
         small.calving(calv, hflx)
     small.close()
+
+
+@pytest.mark.gpu
+def test_calving_under_the_slow_lane_schedule():
+    """new bergs appended between steps of the slow-lane schedule (two streams, bergs handed over to the side stream,
+    re-binning inside the step) take part like uploaded ones: same result as the oracle's serial sequence"""
+    import torch
+    import parity as P
+    from icebergs_amd.distributed import PipelinedStepper
+    from icebergs_amd.framework import Icebergs
+    grid, p, cp, b = _setup(n=6000, ni=360, nj=200)
+    orc = O.Oracle(grid, p)
+    st = orc.new_calving_state()
+    cap = 60000
+    ib = Icebergs(grid, p, capacity=cap)
+    ib.set_stream(torch.cuda.current_stream().cuda_stream)
+    ib.set_forcing(grid["forcing"])
+    ib.set_calving_params(cp)
+    bergs = _with_room(b, cap)
+    ib.upload_bergs(b)
+    dev = torch.device("cuda", 0)
+    forcing_dev = [torch.from_numpy(np.ascontiguousarray(grid["forcing"][name])).to(dev) for name in T.FORCING_NAMES]
+    stepper = PipelinedStepper(ib, p, None, slow_lane=True, resort_interval=3)
+    assert stepper.lib_orders
+    for step in range(8):
+        calv, hflx = S.coupler_calving(grid, seed=step % 3, frac=0.01)
+        orc.calving(cp, calv, hflx, st, bergs, cap)
+        orc.run_step(bergs, 1)
+        stepper.flush()
+        ib.calving(calv, hflx)
+        stepper.set_forcing_device([t.data_ptr() for t in forcing_dev])
+        stepper.step()
+    stepper.flush()
+    torch.cuda.synchronize()
+    acc, out, scal = ib.fetch()
+    got = (ib.download_bergs(), acc.copy(), out.copy(), scal.copy())
+    ref = (bergs, orc.acc.copy(), orc.out.copy(), orc.scalars.copy())
+    assert bergs["_n"] > 8000
+    P.compare(ref, got, "calving under the slow lane", params=p)
+    ib.close()

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
     ap.add_argument("--resort", type=int, default=12, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
+    ap.add_argument("--advance-clock", action="store_true", help="kid_set_params with an advancing current_yearday before every step, as a model run does")
     ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=16)
@@ -119,6 +120,9 @@ def main():
         nreduced = stepper.planes.numel()
 
     def step():
+        if args.advance_clock:
+            params.current_yearday += params.dt / 86400.0
+            ib.set_params(params)
         stepper.set_forcing_device(forcing_ptrs)     # applied by the step's prepass: per-cell forcing records + accumulator zeroing
         stepper.step()                               # per-berg kernels; RCCL all-reduce (N>1); 9-point gather
 

@@ -12,11 +12,13 @@
 !!   calving_hflx (nic, njc).
 !! Output: KID_NFORCING planes (kid_get_forcing), stored_ice (10 planes), stored_heat, real_calving (10), grd%calving,
 !!   grd%calving_hflx, KID_NCALV_SCALARS of the last call, int64 n_slots, the berg arrays.
+!! With a third argument (a directory) the restart files and one trajectory sample are written there before the download.
 program kid_couple
   use, intrinsic :: iso_c_binding
   use kid_hip_mod
   implicit none
-  character(len=1024) :: fin, fout
+  character(len=1024) :: fin, fout, rdir
+  type(kid_traj_params) :: tp
   type(kid_grid_desc) :: gd
   type(kid_params) :: par
   type(kid_calving_params) :: cp
@@ -41,6 +43,8 @@ program kid_couple
   end if
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
+  rdir = ''
+  if (command_argument_count() >= 3) call get_command_argument(3, rdir)
   open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old', action='read')
   read(u) magic
   if (magic /= 1263093762) error stop 'kid_couple: bad magic'
@@ -119,6 +123,17 @@ program kid_couple
   call kid_check(kid_get_calving_state(h, c_loc(stored_ice), c_loc(stored_heat), c_loc(rm), c_loc(rmh), c_loc(real_calving)), h, &
                  'kid_get_calving_state')
   call kid_check(kid_get_calving(h, c_loc(gcalv), c_loc(ghflx)), h, 'kid_get_calving')
+  if (len_trim(rdir) > 0) then
+    ! write_restart_bergs (icebergs_fms2io.F90:124-631) and one trajectory sample + write_trajectory (FW:5328, IO2:1631)
+    ! straight from the device-resident state
+    tp%traj_area_thres = 0. ; tp%traj_area_thres_sntbc = 0. ; tp%traj_area_thres_fl = 1.e9 ; tp%save_all_traj_year = 1.e30
+    tp%save_traj_by_class_start_mass_thres_s = 0. ; tp%save_traj_by_class_start_mass_thres_n = 0.
+    tp%save_short_traj = 1 ; tp%save_fl_traj = 1 ; tp%save_nonfl_traj_by_class = 0 ; tp%pad = 0
+    call kid_check(kid_set_traj_params(h, tp), h, 'kid_set_traj_params')
+    call kid_check(kid_record_posn(h), h, 'kid_record_posn')
+    call kid_check(kid_write_trajectories(h, trim(rdir)//'/iceberg_trajectories.nc'//c_null_char), h, 'kid_write_trajectories')
+    call kid_check(kid_write_restart(h, trim(rdir)//c_null_char), h, 'kid_write_restart')
+  end if
   call kid_check(kid_num_bergs(h, n_slots, n_alive), h, 'kid_num_bergs')
   soa%n = n_slots
   call kid_check(kid_download_bergs(h, soa), h, 'kid_download_bergs')

@@ -148,7 +148,9 @@ def test_fortran_coupling_front_end(oracle, tmp_path, staggers):
         for a in calls:
             for name in ("uo", "ui", "vo", "vi", "tauxa", "tauya", "ssh", "cn", "hi", "sst", "sss", "calving", "calving_hflx"):
                 f.write(np.ascontiguousarray(a[name], dtype=np.float64).tobytes())
-    r = subprocess.run([COUPLE, case, res], capture_output=True, text=True, timeout=300)
+    rdir = tmp_path / "RESTART"
+    rdir.mkdir()
+    r = subprocess.run([COUPLE, case, res, str(rdir)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout
     # the same sequence on the oracle
     orc = O.Oracle(grid, p)
@@ -194,3 +196,17 @@ def test_fortran_coupling_front_end(oracle, tmp_path, staggers):
     for name in ("lon", "lat", "uvel", "vvel", "mass", "thickness", "heat_density", "start_day"):
         rv, gv = bergs[name][:bergs["_n"]][ra][ro], gb[name][ga][go]
         assert np.allclose(gv, rv, rtol=1e-10, atol=1e-12), (name, float(np.abs(gv - rv).max()))
+    # the files the Fortran driver wrote from the resident state (write_restart_bergs, write_trajectory), read independently
+    from scipy.io import netcdf_file
+    with netcdf_file(str(rdir / "icebergs.res.nc"), "r", mmap=False) as f:
+        ident = (f.variables["id_cnt"][:].astype(np.int64) << 32) + f.variables["id_ij"][:].astype(np.int64)
+        of = np.argsort(ident)
+        assert np.array_equal(ident[of], gb["id"][ga][go])
+        for name in ("lon", "lat", "mass", "thickness", "heat_density"):
+            assert np.array_equal(f.variables[name][:][of], gb[name][ga][go]), name
+    with netcdf_file(str(rdir / "calving.res.nc"), "r", mmap=False) as f:
+        nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+        sl = (slice(d.jsc - d.jsd, d.jec - d.jsd + 1), slice(d.isc - d.isd, d.iec - d.isd + 1))
+        assert np.array_equal(f.variables["stored_ice"][0], g_ice[:, sl[0], sl[1]]) and np.array_equal(f.variables["stored_heat"][0], g_heat[sl])
+    with netcdf_file(str(rdir / "iceberg_trajectories.nc"), "r", mmap=False) as f:
+        assert f.variables["lon"].shape == (int(ga.sum()),) and list(f.variables)[:6] == ["lon", "lat", "year", "day", "id_cnt", "id_ij"]

@@ -1209,8 +1209,12 @@ static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_
   std::swap(h->bp.id, h->bp_alt.id);
   for (int f = 0; f < KID_NB_I32; ++f) std::swap(h->bp.i[f], h->bp_alt.i[f]);
   KID_HIP(h, hipGetLastError());
-  h->tables_dirty = true;
-  return refresh_tables(h);
+  if (h->tables_dirty) return refresh_tables(h);
+  // only the field pointers changed: one table, not four (a launch on the side stream may still be reading it)
+  { const int rc = join_side(h); if (rc) return rc; }
+  hipLaunchKernelGGL(set_berg_table_kernel, dim3(1), dim3(64), 0, h->stream, h->bp, h->d_bp);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
 }
 int kid_set_resort_interval(kid_handle *h, int steps) {
   if (!h || steps < 0) return KID_EINVAL;

@@ -217,7 +217,26 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       } else {
         // a berg whose cell leaves the computational domain is packed-and-deleted by send_bergs_to_other_pes on a
         // PE without that neighbour (FW:3024-3041)
-        if (d.ine < g.isc || d.ine > g.iec || d.jne < g.jsc || d.jne > g.jec) t.alive = false;
+        if (d.ine < g.isc || d.ine > g.iec || d.jne < g.jsc || d.jne > g.jec) {
+          bool back = false;
+          if constexpr (!FAST) {  // (a berg of the hot build never changes its cell)
+            // periodic_reentry: the zonal seam treated as a boundary between two PEs: sent east/west (FW:3024-3041),
+            // unpacked on the other side with *_old reset (FW:3573-3577), the cell one period away accepted by the
+            // modulo-aware point-in-cell test (check_and_find_cell FW:3628), xi / yj recomputed (FW:3634), lon unchanged
+            const int nic = g.iec - g.isc + 1;
+            const int i2 = d.ine > g.iec ? d.ine - nic : (d.ine < g.isc ? d.ine + nic : d.ine);
+            if (p.periodic_reentry && g.Lx > 0. && d.jne >= g.jsc && d.jne <= g.jec && i2 >= g.isc && i2 <= g.iec) {
+              const GlbCell cell2{g, g.idx(i2, d.jne)};
+              int perr = 0; bool pbail = false;
+              double xi2, yj2;
+              if (!pos_within_cell<false>(g, p, cell2, d.lon, d.lat, i2, d.jne, xi2, yj2, perr, pbail)) err = 1;  // not in the cell one period away: 'can not find a cell to place berg in!' FW:3660
+              d.ine = i2; d.xi = xi2; d.yj = yj2;
+              b.f[KID_B_UVEL_OLD][kk] = d.uvel; b.f[KID_B_VVEL_OLD][kk] = d.vvel; b.f[KID_B_LON_OLD][kk] = d.lon; b.f[KID_B_LAT_OLD][kk] = d.lat;
+              back = true;
+            }
+          }
+          if (!back) t.alive = false;
+        }
         b.f[KID_B_LON][kk] = d.lon; b.f[KID_B_LAT][kk] = d.lat; b.f[KID_B_UVEL][kk] = d.uvel; b.f[KID_B_VVEL][kk] = d.vvel;
         b.f[KID_B_AXN][kk] = d.axn; b.f[KID_B_AYN][kk] = d.ayn; b.f[KID_B_BXN][kk] = d.bxn; b.f[KID_B_BYN][kk] = d.byn;
         b.f[KID_B_XI][kk] = d.xi; b.f[KID_B_YJ][kk] = d.yj;
@@ -347,9 +366,12 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
   const int c = g.idx(i, j), ni = g.ni;
   const double a = g.geo[c].area, m = g.geo[c].msk;
   const int dm = p.diag_mask;
+  const bool wrap = p.periodic_reentry != 0 && g.Lx > 0.;
   auto nine = [&](int base) {
     const double *v = acc + (size_t)base * ncell;
-#define KID_V(di, dj, s) v[(size_t)((s) - 1) * ncell + (size_t)(c + (di) + (dj) * ni)]
+    // periodic_reentry: the neighbour column across the zonal seam (mpp_update_domains of var_on_ocean, IB:6103)
+    const int wm = (wrap && i == g.isc) ? nic : 0, wp = (wrap && i == g.iec) ? -nic : 0;
+#define KID_V(di, dj, s) v[(size_t)((s) - 1) * ncell + (size_t)(c + (di) + ((di) < 0 ? wm : ((di) > 0 ? wp : 0)) + (dj) * ni)]
     double dmda = KID_V(0, 0, 5) + (((KID_V(-1, -1, 9) + KID_V(1, 1, 1)) + (KID_V(1, -1, 7) + KID_V(-1, 1, 3)))
                                    + ((KID_V(-1, 0, 6) + KID_V(1, 0, 4)) + (KID_V(0, -1, 8) + KID_V(0, 1, 2))));
 #undef KID_V
@@ -391,7 +413,7 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
 }
 
 // sum_up_spread_fields(.., 'mass') alone (IB:6126-6138) into a plane of its own: grd%spread_mass_old, IB:5495-5497
-__global__ void __launch_bounds__(256) mass_gather_kernel(const DevGrid g, const double *__restrict__ acc, double *__restrict__ plane, const size_t ncell) {
+__global__ void __launch_bounds__(256) mass_gather_kernel(const DevGrid g, const double *__restrict__ acc, double *__restrict__ plane, const size_t ncell, const bool wrap) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int nic = g.iec - g.isc + 1, njc = g.jec - g.jsc + 1;
   if (t >= nic * njc) return;
@@ -399,7 +421,8 @@ __global__ void __launch_bounds__(256) mass_gather_kernel(const DevGrid g, const
   const int c = g.idx(i, j), ni = g.ni;
   const double a = g.geo[c].area, m = g.geo[c].msk;
   const double *v = acc + (size_t)KID_A_MASS_ON_OCEAN * ncell;
-#define KID_V(di, dj, s) v[(size_t)((s) - 1) * ncell + (size_t)(c + (di) + (dj) * ni)]
+  const int wm = (wrap && i == g.isc) ? nic : 0, wp = (wrap && i == g.iec) ? -nic : 0;
+#define KID_V(di, dj, s) v[(size_t)((s) - 1) * ncell + (size_t)(c + (di) + ((di) < 0 ? wm : ((di) > 0 ? wp : 0)) + (dj) * ni)]
   double dmda = KID_V(0, 0, 5) + (((KID_V(-1, -1, 9) + KID_V(1, 1, 1)) + (KID_V(1, -1, 7) + KID_V(-1, 1, 3)))
                                  + ((KID_V(-1, 0, 6) + KID_V(1, 0, 4)) + (KID_V(0, -1, 8) + KID_V(0, 1, 2))));
 #undef KID_V
@@ -1110,6 +1133,7 @@ static bool field_never_written(const kid_handle *h, int f) {
   switch (f) {
     case KID_B_AXN_FAST: case KID_B_AYN_FAST: case KID_B_BXN_FAST: case KID_B_BYN_FAST: case KID_B_ANG_VEL: case KID_B_ANG_ACCEL: case KID_B_ROT:
     case KID_B_UVEL_OLD: case KID_B_VVEL_OLD: case KID_B_LON_OLD: case KID_B_LAT_OLD:
+      return p.periodic_reentry == 0;   // a berg that re-enters across the seam gets them reset (FW:3573-3577)
     case KID_B_HALO_BERG: case KID_B_STATIC_BERG: case KID_B_START_LON: case KID_B_START_LAT: case KID_B_START_MASS: case KID_B_HEAT_DENSITY:
       return true;
     case KID_B_UVEL_PREV: case KID_B_VVEL_PREV:
@@ -1542,7 +1566,8 @@ int kid_step_local(kid_handle *h) {
     h->flags = keep;
     if (rc) return rc;
     { const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
-      hipLaunchKernelGGL(mass_gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), (const double *)h->d_acc, h->d_spread_mass_old, h->ncell); }
+      hipLaunchKernelGGL(mass_gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), (const double *)h->d_acc, h->d_spread_mass_old, h->ncell,
+                         h->params.periodic_reentry != 0 && h->gd.Lx > 0.); }
     KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
   }

@@ -340,7 +340,13 @@ typedef struct kid_params {
   int32_t rev_mind;                     /* FW:59 */
   int32_t rotate_icebergs_for_mass_spreading; /* FW:750: hexagon orientation from the bonds (IB:4004) */
   int32_t diag_mask;                    /* KID_DIAG_* : which `id_*>0` guards are on */
-  int32_t pad1[2];                      /* explicit: no implicit tail padding (Fortran stream I/O moves components) */
+  int32_t periodic_reentry;             /* the handle owns the whole zonal period (Lx > 0): a berg that leaves through the east or
+                                           west edge of the computational domain re-enters on the other side the way it does where the
+                                           seam is a boundary between two PEs (send_bergs_to_other_pes FW:3024-3041 ->
+                                           unpack_berg_from_buffer2 FW:3573-3577, 3628-3635), and the 9-point gather reads across the
+                                           seam (mpp_update_domains in sum_up_spread_fields, IB:6103).  0: the berg is removed, as
+                                           on a PE without that neighbour */
+  int32_t pad1;                         /* explicit: no implicit tail padding (Fortran stream I/O moves components) */
 } kid_params;
 
 #ifdef __cplusplus

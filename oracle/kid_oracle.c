@@ -745,7 +745,21 @@ void ko_evolve_icebergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b, 
     nerr += err;
     int i = b->i32[KID_BI_INE][k], j = b->i32[KID_BI_JNE][k];
     if (i < g->d.isc || i > g->d.iec || j < g->d.jsc || j > g->d.jec) {
-      if (b->i32[KID_BI_ALIVE]) b->i32[KID_BI_ALIVE][k] = 0;
+      const int nic = g->d.iec - g->d.isc + 1;
+      const int i2 = i > g->d.iec ? i - nic : (i < g->d.isc ? i + nic : i);
+      if (p->periodic_reentry && g->d.Lx > 0. && j >= g->d.jsc && j <= g->d.jec && i2 >= g->d.isc && i2 <= g->d.iec) {
+        /* the seam as a boundary between two PEs: the berg is sent east/west (FW:3024-3041) and unpacked on the other side
+         * with its *_old fields reset (FW:3573-3577), its cell found there (check_and_find_cell, FW:3628: the modulo-aware
+         * point-in-cell test accepts the cell one period away) and xi, yj recomputed (FW:3634); lon itself is not changed */
+        const double lon = b->f64[KID_B_LON][k], lat = b->f64[KID_B_LAT][k];
+        PUT(b, KID_B_UVEL_OLD, k, b->f64[KID_B_UVEL][k]); PUT(b, KID_B_VVEL_OLD, k, b->f64[KID_B_VVEL][k]);
+        PUT(b, KID_B_LON_OLD, k, lon); PUT(b, KID_B_LAT_OLD, k, lat);
+        double xi, yj; int perr = 0;
+        if (!ko_is_point_in_cell(g, lon, lat, i2, j)) nerr += 1;   /* 'can not find a cell to place berg in!' FW:3660 */
+        (void)ko_pos_within_cell(g, p, lon, lat, i2, j, &xi, &yj, &perr);
+        b->i32[KID_BI_INE][k] = i2;
+        PUT(b, KID_B_XI, k, xi); PUT(b, KID_B_YJ, k, yj);
+      } else if (b->i32[KID_BI_ALIVE]) b->i32[KID_BI_ALIVE][k] = 0;
     }
   }
   if (scalars) { scalars[KID_S_NSPEEDING_TICKETS] += (double)tickets; scalars[KID_S_ERROR_COUNT] += (double)nerr; }
@@ -1372,10 +1386,13 @@ void ko_thermodynamics(const ko_grid *g, const kid_params *p, kid_berg_soa *b, d
  * IB:3390-3489 create_gridded_icebergs_fields = calculate_mass_on_ocean (IB:4970-5011, with
  * calculate_sum_over_bergs_diagnositcs IB:5014-5071) + sum_up_spread_fields (IB:6077-6150) + ustar
  * ---------------------------------------------------------------------------------------------- */
+static int g_wrap_x = 0;   /* periodic_reentry: mpp_update_domains(var_on_ocean) of IB:6103 on a rank that owns the whole zonal period */
 static void sum_up_spread_field(const ko_grid *g, const double *acc, int base, int is_area, double *field) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
+  const int nic_w = g->d.iec - g->d.isc + 1;
   memset(field, 0, ncell * sizeof(double));
-#define V(i, j, s) acc[(size_t)(base + (s) - 1) * ncell + GIDX(g, i, j)]
+#define WI(i) ((g_wrap_x && (i) < g->d.isc) ? (i) + nic_w : ((g_wrap_x && (i) > g->d.iec) ? (i) - nic_w : (i)))
+#define V(i, j, s) acc[(size_t)(base + (s) - 1) * ncell + GIDX(g, WI(i), j)]
   for (int j = g->d.jsc; j <= g->d.jec; ++j)
     for (int i = g->d.isc; i <= g->d.iec; ++i) {
       double dmda = V(i, j, 5) + (((V(i - 1, j - 1, 9) + V(i + 1, j + 1, 1)) + (V(i + 1, j - 1, 7) + V(i - 1, j + 1, 3)))
@@ -1449,6 +1466,7 @@ void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double
   double *o_mass = out + (size_t)KID_O_SPREAD_MASS * ncell, *o_area = out + (size_t)KID_O_SPREAD_AREA * ncell;
   double *o_u = out + (size_t)KID_O_SPREAD_UVEL * ncell, *o_v = out + (size_t)KID_O_SPREAD_VVEL * ncell;
   double *o_us = out + (size_t)KID_O_USTAR_ICEBERG * ncell;
+  g_wrap_x = p->periodic_reentry && g->d.Lx > 0.;
   memset(o_u, 0, ncell * sizeof(double)); memset(o_v, 0, ncell * sizeof(double)); memset(o_area, 0, ncell * sizeof(double));
   if ((dm & KID_DIAG_SPREAD_UVEL) || p->pass_fields_to_ocean_model) sum_up_spread_field(g, acc, KID_A_UVEL_ON_OCEAN, 0, o_u);
   if ((dm & KID_DIAG_SPREAD_VVEL) || p->pass_fields_to_ocean_model) sum_up_spread_field(g, acc, KID_A_VVEL_ON_OCEAN, 0, o_v);
@@ -1529,6 +1547,7 @@ void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t
   if (p->find_melt_using_spread_mass) {  /* IB:5490-5503 (the Iceberg_melt_without_decay variant, IB:3225/3411, is not restated) */
     g_mass_only = 1; ko_calculate_mass_on_ocean(g, p, b, acc); g_mass_only = 0;
     spread_mass_old = (double *)calloc(ncell, sizeof(double));
+    g_wrap_x = p->periodic_reentry && g->d.Lx > 0.;
     sum_up_spread_field(g, acc, KID_A_MASS_ON_OCEAN, 0, spread_mass_old);
     for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
   }

@@ -395,6 +395,44 @@ def test_find_melt_using_spread_mass(oracle, variant):
     assert np.abs(ref[1][k]).max() > 0 and not np.allclose(ref[1][k], plain[1][k], rtol=1e-3)   # it IS a different flux
 
 
+@pytest.mark.parametrize("verlet", [False, True])
+def test_periodic_reentry(oracle, verlet):
+    """periodic_reentry=1 on the zonally cyclic config-2 grid: bergs driven across the seam in both directions come back on
+    the other side (cell index one period away, lon unchanged, xi / yj recomputed) and the 9-point gather reads across the
+    seam; without the switch the same bergs are removed"""
+    from icebergs_amd import types as T
+    grid = S.c2_forcing(S.latlon_grid())
+    grid["forcing"]["uo"][:] = np.where(grid["static"]["lat"] > 0, 1.5, -1.5)    # eastward north of the equator, westward south of it
+    grid["forcing"]["vo"][:] = 0.0
+    p = S.default_params()
+    p.dt = 1800.0
+    S.set_diag_all(p)
+    if verlet:
+        p.Runge_not_Verlet = 0
+    b1 = S.place_bergs(grid, 1500, 61, (356, 360), (120, 180))     # next to the east edge, northern hemisphere
+    b2 = S.place_bergs(grid, 1500, 62, (1, 5), (20, 80))           # next to the west edge, southern hemisphere
+    b = {k: np.concatenate([b1[k], b2[k]]) for k in b1}
+    b["id"] = np.arange(1, 3001, dtype=np.int64)
+    q = S.params_copy(p)
+    q.periodic_reentry = 1
+    nsteps = 60
+    ref, got = _both(grid, q, b, nsteps, "fused")
+    P.compare(ref, got, "periodic re-entry/verlet=%s" % verlet, params=q)
+    gb = got[0]
+    alive = gb["alive"] != 0
+    assert alive.sum() == 3000                                     # nobody is lost
+    o = np.argsort(gb["id"])
+    east_start = (b["ine"] > 300)
+    crossed_e = east_start & (gb["ine"][o] < 100) & (gb["lon"][o] > 360.0)   # back in the low columns, longitude still counting up
+    crossed_w = (~east_start) & (gb["ine"][o] > 300)
+    assert crossed_e.sum() > 200 and crossed_w.sum() > 200
+    sm = got[2][T.ENUMS["KID_O_SPREAD_MASS"]]
+    d = grid["desc"]
+    assert sm[:, d.isc - d.isd].max() > 0 and sm[:, d.iec - d.isd].max() > 0   # mass on both sides of the seam
+    lost = P.run_hip(grid, p, b, nsteps)                                        # the default: removed at the edge
+    assert (lost[0]["alive"] != 0).sum() < 3000 - 400
+
+
 def test_slow_lane_with_collective_matches_plain(oracle):
     """the N>1 code path of the slow-lane schedule (RCCL all-reduce + gather on a third stream), rehearsed with one
     rank: must give what the serial single-stream sequence gives"""

@@ -138,7 +138,8 @@ int kid_get_calving(kid_handle *h, double *calving, double *calving_hflx);
 int kid_restart_write_bergs(const char *path, const kid_params *p, const kid_berg_soa *host);
 int kid_restart_count_bergs(const char *path, int64_t *n);
 /* fills the arrays of `host` (room for `capacity` rows): the file's fields, zeros elsewhere, *_old = current values and
- * halo_berg = 0 as read_restart_bergs sets them (IO2:895-925); xi / yj need the grid and are left to kid_read_restart */
+ * halo_berg = 0 as read_restart_bergs sets them (IO2:895-925); xi / yj need the grid and are left to kid_read_restart,
+ * and so are the ids of a file with the old 32-bit iceberg_num (they come back 0 here; generate_id needs the counters) */
 int kid_restart_read_bergs(const char *path, kid_berg_soa *host, int64_t capacity);
 /* bonds_iceberg.res.nc (IO2:466-583, read_restart_bonds IO2:1190-1481): one record per bond side; `bergs` gives the ids
  * and cells of both ends.  Reading puts every bond at the head of its berg's list, as form_a_bond does. */

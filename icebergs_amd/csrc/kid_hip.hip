@@ -32,7 +32,7 @@ using namespace kid;
 
 namespace {
 
-enum : unsigned { PH_INTERP = 1u, PH_EVOLVE = 2u, PH_THERMO = 4u, PH_SPREAD = 8u, PH_FL = 16u };   // PH_FL: footloose_calving between evolve and thermodynamics
+enum : unsigned { PH_INTERP = 1u, PH_EVOLVE = 2u, PH_THERMO = 4u, PH_SPREAD = 8u, PH_FL = 16u, PH_TSPREAD = 32u };   // PH_FL: footloose_calving between evolve and thermodynamics
 
 struct BergPtrs {
   double *f[KID_NB_F64];
@@ -289,7 +289,10 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       KID_PHASE_FENCE();
       KID_MARK("thermo_interp_done");
       const BergThermo before = t;
-      thermodynamics(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
+      if constexpr ((PH & PH_TSPREAD) != 0) {  // thermodynamics spreads the would-be masses itself, IB:3219-3238
+        const TSpreadArgs ts{d.xi, d.yj, b.orient ? b.orient[kk] : p.initial_orientation, fl.footprint != 0};
+        thermodynamics<true>(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal, &ts);
+      } else thermodynamics(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
       if (active) {
         b.f[KID_B_MASS][kk] = t.M; b.f[KID_B_THICKNESS][kk] = t.T; b.f[KID_B_WIDTH][kk] = t.W; b.f[KID_B_LENGTH][kk] = t.L;
         if (t.mass_of_bits != before.mass_of_bits) b.f[KID_B_MASS_OF_BITS][kk] = t.mass_of_bits;
@@ -354,7 +357,7 @@ __global__ void set_grid_kernel(const DevGrid src, DevGrid *dst) { if (threadIdx
 // -------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_params p, double *__restrict__ acc,
                                                      double *__restrict__ out, const size_t ncell, double *__restrict__ totals,
-                                                     const double *__restrict__ spread_mass_old) {
+                                                     const double *__restrict__ spread_mass_old, const double *__restrict__ spread_mass_tmp) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < KID_NSCALAR) {  // fold this step's increments into the running totals kept on `bergs` (IB:3130, 3295)
     totals[t] += acc[(size_t)KID_NACC * ncell + t];
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
   }
   out[(size_t)KID_O_USTAR_ICEBERG * ncell + c] = ustar_h;
   if (spread_mass_old)  // find_melt_using_spread_mass: the melt flux is what the gridded mass lost over the step, IB:3436-3445
-    acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = (a > 0.0) ? dmax((spread_mass_old[c] - sm) / p.dt, 0.0) : 0.0;
+    acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = (a > 0.0) ? dmax((spread_mass_old[c] - (spread_mass_tmp ? spread_mass_tmp[c] : sm)) / p.dt, 0.0) : 0.0;
   if (p.apply_thickness_cutoff_to_gridded_melt && (p.melt_cutoff >= 0.) && (sa > 0.)) {  // IB:3477-3488 (comp. domain)
     const double ave_thickness = sm / (sa * p.rho_bergs);
     const double ave_draft = ave_thickness * (p.rho_bergs / RHO_SEAWATER);
@@ -659,8 +662,8 @@ static int check_params(kid_handle *h, const kid_params *p) {
   // fills mass/area/Uvel/Vvel_on_ocean, but calculate_mass_on_ocean zeroes those planes again (IB:4984-4987) without
   // refilling them (IB:4997), and nothing reads them in between: the reference's spread_mass is identically zero in
   // this mode.  So the stage spreading is not launched and the spreading phase skips the berg (berg_kernel, PH_SPREAD).
-  if (p->find_melt_using_spread_mass && (p->Iceberg_melt_without_decay || p->mts || p->interactive_icebergs_on || p->footloose)) {
-    h->err = "find_melt_using_spread_mass is implemented for the plain evolve loop only (no Iceberg_melt_without_decay, bonds, interactions or footloose)";
+  if (p->find_melt_using_spread_mass && (p->mts || p->interactive_icebergs_on || p->footloose)) {
+    h->err = "find_melt_using_spread_mass is implemented for the plain evolve loop only (no bonds, interactions or footloose)";
     return KID_EUNSUPPORTED;
   }
   if (p->footloose && p->displace_fl_bergs) { h->err = "footloose with displace_fl_bergs needs FMS's random stream: use displace_fl_bergs=F"; return KID_EUNSUPPORTED; }
@@ -1481,7 +1484,8 @@ static int launch_gather(kid_handle *h) {
   const DevGrid g = dev_grid(h);
   const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, g, h->params, h->d_acc, h->d_out, h->ncell, h->d_totals,
-                     (const double *)(h->params.find_melt_using_spread_mass ? h->d_spread_mass_old : nullptr));
+                     (const double *)(h->params.find_melt_using_spread_mass ? h->d_spread_mass_old : nullptr),
+                     (const double *)((h->params.find_melt_using_spread_mass && h->params.Iceberg_melt_without_decay) ? h->d_spread_mass_old + h->ncell : nullptr));
   KID_HIP(h, hipGetLastError());
   return KID_OK;
 }
@@ -1556,7 +1560,7 @@ int kid_step_local(kid_handle *h) {
     // IB:5490-5503: the gridded mass BEFORE the thermodynamics (calculate_mass_on_ocean without diagnostics, the 'mass'
     // gather into grd%spread_mass_old, planes reset), then thermodynamics + create_gridded_icebergs_fields as usual; the
     // gather replaces floating_melt by (spread_mass_old - spread_mass)/dt (IB:3436-3445)
-    if (!h->d_spread_mass_old) { KID_HIP(h, hipMalloc(&h->d_spread_mass_old, h->ncell * sizeof(double))); KID_HIP(h, hipMemsetAsync(h->d_spread_mass_old, 0, h->ncell * sizeof(double), h->stream)); }
+    if (!h->d_spread_mass_old) { KID_HIP(h, hipMalloc(&h->d_spread_mass_old, 2 * h->ncell * sizeof(double))); KID_HIP(h, hipMemsetAsync(h->d_spread_mass_old, 0, 2 * h->ncell * sizeof(double), h->stream)); }  // + spread_mass_tmp
     if (!p.static_icebergs) { rc = p.old_interp_flds_order ? launch_berg<PH_EVOLVE>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h); if (rc) return rc; }
     const size_t on_ocean = (size_t)KID_A_MASS_ON_OCEAN * h->ncell, on_bytes = 36 * h->ncell * sizeof(double);
     KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
@@ -1569,6 +1573,17 @@ int kid_step_local(kid_handle *h) {
       hipLaunchKernelGGL(mass_gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), (const double *)h->d_acc, h->d_spread_mass_old, h->ncell,
                          h->params.periodic_reentry != 0 && h->gd.Lx > 0.); }
     KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
+    if (p.Iceberg_melt_without_decay) {
+      // the bergs do not decay, so the gridded mass AFTER the melt is what thermodynamics itself spreads (IB:3219-3238);
+      // it is gathered into spread_mass_tmp (IB:3411-3413) before create_gridded_icebergs_fields spreads the unchanged bergs
+      rc = p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_TSPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_TSPREAD>(h);
+      if (rc) return rc;
+      { const int ncomp = (h->gd.iec - h->gd.isc + 1) * (h->gd.jec - h->gd.jsc + 1);
+        hipLaunchKernelGGL(mass_gather_kernel, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), (const double *)h->d_acc, h->d_spread_mass_old + h->ncell, h->ncell,
+                           h->params.periodic_reentry != 0 && h->gd.Lx > 0.); }
+      KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
+      return launch_berg<PH_SPREAD>(h);
+    }
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
   }
   if (p.old_interp_flds_order) {

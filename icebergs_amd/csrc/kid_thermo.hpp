@@ -146,9 +146,16 @@ __device__ __forceinline__ int minloc_abs10(const double *tab, double v) {  // F
 
 // IB:2844-3300 thermodynamics for one berg.  Writes the new state into `b`, scatters into acc planes.
 template <class CELL>
+__device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
+                                            int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg, bool footprint, double theta);
+// TSPREAD (find_melt_using_spread_mass with Iceberg_melt_without_decay, IB:3219-3238): the masses the berg WOULD have after
+// the step are spread onto the ocean from inside thermodynamics, before the berg is put back to what it was.  A compile-
+// time switch: the spreading code is inlined only into the launches of that namelist combination.
+struct TSpreadArgs { double xi, yj, theta; bool footprint; };
+template <bool TSPREAD = false, class CELL>
 __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_params &p, const CELL &cellv, BergThermo &b, const Env &e,
                                                double uvel, double vvel, double lat, int i, int j, bool active,
-                                               double *acc, size_t ncell, Seg &seg, double *scal) {
+                                               double *acc, size_t ncell, Seg &seg, double *scal, const TSpreadArgs *ts = nullptr) {
   constexpr double perday = 1. / 86400.;
   const double dt = p.dt;
   const int c = g.idx(i, j);
@@ -312,7 +319,18 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   }
   unsigned nerr = (active && area == 0.) ? 1u : 0u;  // FATAL 'berg appears to have grounded!' IB:3207
   if (p.allow_bergs_to_roll && N_bonds == 0.) rolling(p, Tn, Wn, Ln);
-  if (p.Iceberg_melt_without_decay) {  // IB:3214-3257 (with find_melt_using_spread_mass the reference also spreads the new masses here, IB:3225: refused at kid_create)
+  if (p.Iceberg_melt_without_decay) {  // IB:3214-3257
+    if constexpr (TSPREAD) {  // IB:3219-3238
+      BergThermo nb = b;
+      nb.mass_of_fl_bits = Mnew_fl; nb.mass_of_fl_bergy_bits = nMbits_fl;
+      if (Mnew > 0.) { nb.M = Mnew; nb.mass_of_bits = nMbits; nb.L = Ln; nb.W = Wn; nb.T = Tn; }
+      else {  // the parent is gone but footloose bits remain: they stand in for it (addfootloose=.false.)
+        const double M_edit = Lnfl * Wnfl * Tnfl * p.rho_bergs;
+        nb.M = M_edit; nb.mass_of_bits = nMbits; nb.mass_scaling = Mnew_fl * ms / M_edit; nb.L = Lnfl; nb.W = Wnfl; nb.T = Tnfl;
+        nb.mass_of_fl_bits = 0.; nb.mass_of_fl_bergy_bits = 0.;
+      }
+      spread_mass(g, p, cellv, nb, uvel, vvel, i, j, ts->xi, ts->yj, active && (Mnew > 0. || Mnew_fl > 0.), acc, ncell, seg, ts->footprint, ts->theta);
+    }
     Mnew = M;
     b.fl_k = fl_k;
   } else {

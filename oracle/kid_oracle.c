@@ -1347,7 +1347,20 @@ void ko_thermodynamics(const ko_grid *g, const kid_params *p, kid_berg_soa *b, d
     }
     if (p->allow_bergs_to_roll && N_bonds == 0.) ko_rolling(p, &Tn, &Wn, &Ln);
     if (p->Iceberg_melt_without_decay) {
-      /* IB:3214-3257: state is left unchanged (find_melt_using_spread_mass variant not supported) */
+      /* IB:3214-3257: state is left unchanged; with find_melt_using_spread_mass the would-be masses are spread first (IB:3219-3238) */
+      if (p->find_melt_using_spread_mass && (Mnew > 0. || Mnew_fl > 0.) && area > 0.) {
+        double tb[KID_NB_F64];
+        memcpy(tb, bs, sizeof(tb));
+        tb[KID_B_MASS_OF_FL_BITS] = Mnew_fl; tb[KID_B_MASS_OF_FL_BERGY_BITS] = nMbits_fl;
+        g_orient_use = (g_orient != NULL);
+        if (g_orient) g_orient_now = g_orient[k];
+        if (Mnew > 0.) spread_mass(g, p, acc, tb, i, j, bs[KID_B_XI], bs[KID_B_YJ], Mnew, nMbits, ms, Ln * Wn, Tn, 1);
+        else {
+          const double M_edit = Lnfl * Wnfl * Tnfl * p->rho_bergs, Mscale_edit = Mnew_fl * ms / M_edit;
+          spread_mass(g, p, acc, tb, i, j, bs[KID_B_XI], bs[KID_B_YJ], M_edit, nMbits, Mscale_edit, Lnfl * Wnfl, Tnfl, 0);
+        }
+        g_orient_use = 0;
+      }
       Mnew = bs[KID_B_MASS]; nMbits = bs[KID_B_MASS_OF_BITS];
       Mnew_fl = bs[KID_B_MASS_OF_FL_BITS]; nMbits_fl = bs[KID_B_MASS_OF_FL_BERGY_BITS];
       PUT(b, KID_B_FL_K, k, fl_k);
@@ -1459,6 +1472,7 @@ void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_
 }
 /* the per-cell half: sum_up_spread_fields (IB:6077-6150) + IB:3449-3488.  In a particle-sharded run this is what
  * follows the all-reduce of the accumulators. */
+static const double *g_spread_mass_tmp = NULL;   /* spread_mass_tmp of IB:3411-3413 (Iceberg_melt_without_decay) */
 static const double *g_spread_mass_old = NULL;   /* grd%spread_mass_old while ko_run_step runs with find_melt_using_spread_mass */
 void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double *out) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
@@ -1502,7 +1516,8 @@ void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double
     for (int j = g->d.jsd; j <= g->d.jed; ++j) for (int i = g->d.isd; i <= g->d.ied; ++i) {
       size_t c = GIDX(g, i, j);
       const int in_c = i >= g->d.isc && i <= g->d.iec && j >= g->d.jsc && j <= g->d.jec;
-      acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = (GS(g, KID_G_AREA, i, j) > 0.0) ? dmax((g_spread_mass_old[c] - (in_c ? o_mass[c] : 0.)) / p->dt, 0.0) : 0.0;
+      const double after = g_spread_mass_tmp ? g_spread_mass_tmp[c] : (in_c ? o_mass[c] : 0.);
+      acc[(size_t)KID_A_FLOATING_MELT * ncell + c] = (GS(g, KID_G_AREA, i, j) > 0.0) ? dmax((g_spread_mass_old[c] - after) / p->dt, 0.0) : 0.0;
     }
   }
   if (p->apply_thickness_cutoff_to_gridded_melt) {
@@ -1544,7 +1559,7 @@ void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t
   if (p->footloose) ko_footloose_calving(g, p, b, capacity, acc, scalars);
   if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
   double *spread_mass_old = NULL;
-  if (p->find_melt_using_spread_mass) {  /* IB:5490-5503 (the Iceberg_melt_without_decay variant, IB:3225/3411, is not restated) */
+  if (p->find_melt_using_spread_mass) {  /* IB:5490-5503 */
     g_mass_only = 1; ko_calculate_mass_on_ocean(g, p, b, acc); g_mass_only = 0;
     spread_mass_old = (double *)calloc(ncell, sizeof(double));
     g_wrap_x = p->periodic_reentry && g->d.Lx > 0.;
@@ -1552,10 +1567,16 @@ void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t
     for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
   }
   ko_thermodynamics(g, p, b, acc, scalars);
+  double *spread_mass_tmp = NULL;
+  if (spread_mass_old && p->Iceberg_melt_without_decay) {  /* IB:3411-3413: what thermodynamics spread is the mass after the melt */
+    spread_mass_tmp = (double *)calloc(ncell, sizeof(double));
+    sum_up_spread_field(g, acc, KID_A_MASS_ON_OCEAN, 0, spread_mass_tmp);
+  }
+  g_spread_mass_tmp = spread_mass_tmp;
   g_spread_mass_old = spread_mass_old;   /* IB:3436-3445 happens inside create_gridded_icebergs_fields, before the cutoff of IB:3477 */
   ko_create_gridded_icebergs_fields(g, p, b, acc, out);
-  g_spread_mass_old = NULL;
-  free(spread_mass_old);
+  g_spread_mass_old = NULL; g_spread_mass_tmp = NULL;
+  free(spread_mass_old); free(spread_mass_tmp);
   int64_t alive = 0;
   for (int64_t k = 0; k < b->n; ++k) alive += berg_alive(b, k);
   scalars[KID_S_NBERGS_ALIVE] = (double)alive;

@@ -374,7 +374,7 @@ def test_time_average_weight(oracle, verlet):
     assert np.abs(got[1][T.ENUMS["KID_A_FLOATING_MELT"]]).max() > 0   # the melt fluxes are still there
 
 
-@pytest.mark.parametrize("variant", ["rk4", "verlet_new_order", "cutoff"])
+@pytest.mark.parametrize("variant", ["rk4", "verlet_new_order", "cutoff", "without_decay", "without_decay_new_order"])
 def test_find_melt_using_spread_mass(oracle, variant):
     """find_melt_using_spread_mass=T (IB:5490-5503, 3436-3445): the melt flux handed to the ocean is the gridded mass the
     step lost, max((spread_mass_old - spread_mass)/dt, 0), not the sum of the bergs' own melt terms"""
@@ -386,8 +386,15 @@ def test_find_melt_using_spread_mass(oracle, variant):
         p.Runge_not_Verlet, p.old_interp_flds_order = 0, 0
     if variant == "cutoff":
         p.apply_thickness_cutoff_to_gridded_melt, p.melt_cutoff = 1, 3800.0   # cells whose mean draught exceeds 200 m are cut
+    if variant.startswith("without_decay"):   # the bergs keep their size; thermodynamics spreads what they WOULD weigh (IB:3219-3238)
+        p.Iceberg_melt_without_decay = 1
+        if variant.endswith("new_order"):
+            p.Runge_not_Verlet, p.old_interp_flds_order = 0, 0
     ref, got = _both(grid, p, b, 6, "fused")
     P.compare(ref, got, "find_melt/" + variant, params=p)
+    if variant.startswith("without_decay"):
+        o = np.argsort(got[0]["id"])
+        assert np.array_equal(got[0]["mass"][o], b["mass"][np.argsort(b["id"])])      # nothing decayed
     q = S.params_copy(p)
     q.find_melt_using_spread_mass = 0
     plain = P.run_oracle(grid, q, b, 6)

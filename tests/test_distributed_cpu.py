@@ -88,3 +88,21 @@ def test_two_rank_gloo_matches_single_process(tmp_path, world):
     for name in P.TRAJ_FIELDS + P.SIZE_FIELDS:  # the shards, put back together, are the single-process population
         got = np.concatenate([parts[r]["b_" + name] for r in range(world)])
         assert np.array_equal(got, rb[name]), name
+
+
+def test_sharded_path_refuses_find_melt_using_spread_mass():
+    """grd%spread_mass_old would have to be summed over the ranks as well: the sharded path says so instead of computing
+    a melt flux from a partial sum"""
+    import numpy as np
+    import pytest
+    from icebergs_amd import synthetic as S
+    from icebergs_amd.distributed import accumulator_views
+    from icebergs_amd import types as T
+    p = S.default_params()
+    p.find_melt_using_spread_mass = 1
+    block = np.zeros(T.NACC * 16 + T.NSCALAR)
+    with pytest.raises(NotImplementedError):
+        accumulator_views(block, 16, 0, p)
+    p.find_melt_using_spread_mass = 0
+    planes, scalars = accumulator_views(block, 16, 0, p)
+    assert scalars.size == T.NSCALAR and planes.size % 16 == 0

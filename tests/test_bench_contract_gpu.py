@@ -33,3 +33,19 @@ def test_bench_line_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """the N>1 code path of bench.py (per-rank shards, the three-stream slow-lane stepper with an exchange, barrier + MAX over
+    ranks, one line from rank 0) with two ranks on GPU 0 and gloo instead of RCCL: exercised, not timed"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--bergs", "20000", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stderr[-2000:], r.stdout[-500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["bergs_per_gpu"] == 20000
+    assert abs(d["value"] - 2 * 20000 * 5 / (d["ms_per_step"] * 1e-3 * 5)) / d["value"] < 1e-9      # whole-job aggregate
+    assert "all-reduce" in d["config"]["exchange"] and "cpu_baseline" not in d

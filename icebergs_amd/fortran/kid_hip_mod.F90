@@ -23,7 +23,7 @@ module kid_hip_mod
   public :: kid_calving_params, kid_calving_in, kid_set_calving_params, kid_set_calving_state, kid_get_calving_state
   public :: kid_calving, kid_get_calving, KID_NCALV_SCALARS, KID_NCLASSES
   public :: kid_write_restart, kid_read_restart
-  public :: kid_traj_params, kid_set_traj_params, kid_record_posn, kid_write_trajectories
+  public :: kid_traj_params, kid_set_traj_params, kid_record_posn, kid_write_trajectories, kid_write_bond_trajectories
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
@@ -131,6 +131,11 @@ module kid_hip_mod
       type(c_ptr), value :: h
     end function
     integer(c_int) function kid_write_trajectories(h, path) bind(C, name='kid_write_trajectories')
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function kid_write_bond_trajectories(h, path) bind(C, name='kid_write_bond_trajectories')
       import :: c_int, c_ptr, c_char
       type(c_ptr), value :: h
       character(kind=c_char), intent(in) :: path(*)

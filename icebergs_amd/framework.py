@@ -141,6 +141,15 @@ class Icebergs:
     def write_trajectories(self, path):
         self._check(self.lib.kid_write_trajectories(self.h, str(path).encode()), "kid_write_trajectories")
 
+    def num_bond_traj_records(self):
+        n = C.c_int64()
+        self._check(self.lib.kid_num_bond_traj_records(self.h, C.byref(n)), "kid_num_bond_traj_records")
+        return n.value
+
+    def write_bond_trajectories(self, path):
+        """write_bond_trajectory, IO2:2106-2331 (needs TrajParams.save_bond_traj and uploaded bonds)"""
+        self._check(self.lib.kid_write_bond_trajectories(self.h, str(path).encode()), "kid_write_bond_trajectories")
+
     # ---- restart files (icebergs_fms2io.F90:124-631, 663-1049) ----
     def write_restart(self, directory):
         self._check(self.lib.kid_write_restart(self.h, str(directory).encode()), "kid_write_restart")

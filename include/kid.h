@@ -156,11 +156,16 @@ int kid_read_restart(kid_handle *h, const char *dir);
  * to buffers in HBM, and iceberg_trajectories.nc (icebergs_fms2io.F90:1631-2103) written from them: dimension "i", lon,
  * lat, year, day, id_cnt, id_ij, then the save_fl_traj group, then the long group unless save_short_traj (same names,
  * types and attributes).  kid_write_trajectories appends to an existing file, like the reference, and empties the buffers.
- * Bond trajectories (save_bond_traj) are not recorded. */
+ * With kid_traj_params.save_bond_traj every bond of a sampled berg is sampled too, from each of its two bergs (FW:5456-5490),
+ * and kid_write_bond_trajectories writes / extends bond_trajectories.nc (write_bond_trajectory, icebergs_fms2io.F90:2106-2331:
+ * lon, lat, year, day, length, n1, n2, id_cnt1, id_ij1, id_cnt2, id_ij2 and, with dem, tangd1, tangd2, nstress, sstress,
+ * rel_rotation, broken); with no bond records pending it leaves the file system alone, as the reference does. */
 int kid_set_traj_params(kid_handle *h, const kid_traj_params *tp);
 int kid_record_posn(kid_handle *h);
 int kid_num_traj_records(kid_handle *h, int64_t *n);
 int kid_write_trajectories(kid_handle *h, const char *path);
+int kid_num_bond_traj_records(kid_handle *h, int64_t *n);
+int kid_write_bond_trajectories(kid_handle *h, const char *path);
 
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */

@@ -96,7 +96,7 @@ typedef struct kid_traj_params {
   int32_t save_short_traj;                       /* FW:759 */
   int32_t save_fl_traj;                          /* FW:762 */
   int32_t save_nonfl_traj_by_class;              /* FW:5371 */
-  int32_t pad;
+  int32_t save_bond_traj;                        /* FW:49: also sample every bond of a sampled berg */
 } kid_traj_params;
 
 /* what one kid_calving call adds to the budget scalars of type icebergs (increments; the first two `stored` entries

@@ -102,3 +102,70 @@ def test_short_records_and_save_all_year(tmp_path):
     with netcdf_file(str(path), "r", mmap=False) as f:
         assert list(f.variables) == ["lon", "lat", "year", "day", "id_cnt", "id_ij"] and f.variables["lon"].shape == (2000,)
     ib.close()
+
+
+def test_bond_trajectories(tmp_path):
+    """save_bond_traj (FW:5456-5490, write_bond_trajectory IO2:2106-2331): a bonded DEM conglomerate, sampled twice; the bond
+    records are recomputed with numpy from the downloaded bergs and bonds, then the file is extended by a second write"""
+    from icebergs_amd.framework import Icebergs
+    grid, p, b, bd = S.config_c4(nx=5, ny=7)
+    n, mb = len(b["lon"]), bd["max_bonds"]
+    ib = Icebergs(grid, p, capacity=n)
+    ib.upload_bergs(b)
+    ib.upload_bonds(bd)
+    ib.set_traj_params(_tp(save_bond_traj=1, save_short_traj=0))
+    expect = []
+    for burst in range(2):
+        p.current_year, p.current_yearday = 3, 40.0 + burst
+        ib.set_params(p)
+        ib.run(2)
+        ib.record_posn()
+        bb, dd = ib.download_bergs(), ib.download_bonds(mb)
+        row_of = {int(i): k for k, i in enumerate(bb["id"])}
+        pi_180 = p.pi / 180.0
+        for k in range(n):
+            for s in range(int(dd["count"][k])):
+                q = s * n + k
+                o = row_of[int(dd["other_id"][q])]
+                lat_ref = 0.5 * (bb["lat"][k] + bb["lat"][o])
+                dx_dlon, dy_dlat = (pi_180 * p.Rearth * np.cos(lat_ref * pi_180), pi_180 * p.Rearth) if grid["desc"].grid_is_latlon else (1.0, 1.0)
+                expect.append(dict(
+                    id1=int(bb["id"][k]), id2=int(bb["id"][o]), burst=burst,
+                    lon=0.5 * (bb["lon"][k] + bb["lon"][o]), lat=lat_ref, length=dd["length"][q],
+                    n1=(bb["lon"][k] - bb["lon"][o]) * dx_dlon / bb["length"][k], n2=(bb["lat"][k] - bb["lat"][o]) * dy_dlat / bb["length"][k],
+                    tangd1=dd["tangd1"][q], tangd2=dd["tangd2"][q], nstress=dd["nstress"][q], sstress=dd["sstress"][q],
+                    rel_rotation=dd["rel_rotation"][q], broken=int(dd["broken"][q])))
+    assert len(expect) > 100 and ib.num_bond_traj_records() == len(expect)
+    path = tmp_path / "bond_trajectories.nc"
+    ib.write_bond_trajectories(path)
+    assert ib.num_bond_traj_records() == 0
+    ib.write_bond_trajectories(path)                     # nothing pending: the file is left alone
+    ib.write_trajectories(tmp_path / "iceberg_trajectories.nc")
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        assert list(f.variables) == ["lon", "lat", "year", "day", "length", "n1", "n2", "id_cnt1", "id_ij1", "id_cnt2", "id_ij2",
+                                     "tangd1", "tangd2", "nstress", "sstress", "rel_rotation", "broken"]
+        assert f.variables["nstress"].units == b"Pa" and f.variables["id_cnt1"].long_name == b"counter component of first connected iceberg id"
+        assert f.file_format_major_version == 0 and f.file_format_minor_version == 1
+        got = {name: np.array(f.variables[name][:]) for name in f.variables}
+    assert len(got["lon"]) == len(expect)
+    id1 = (got["id_cnt1"].astype(np.int64) << 32) | (got["id_ij1"].astype(np.int64) & 0xffffffff)
+    id2 = (got["id_cnt2"].astype(np.int64) << 32) | (got["id_ij2"].astype(np.int64) & 0xffffffff)
+    days = np.unique(got["day"])
+    assert len(days) == 2
+    rows = {(int(a), int(c), int(np.searchsorted(days, d))): r for r, (a, c, d) in enumerate(zip(id1, id2, got["day"]))}
+    assert len(rows) == len(expect)
+    for e in expect:
+        r = rows[(e["id1"], e["id2"], e["burst"])]
+        for name in ("lon", "lat", "length", "tangd1", "tangd2", "nstress", "sstress", "rel_rotation"):
+            assert got[name][r] == e[name], (name, got[name][r], e[name])
+        for name in ("n1", "n2"):
+            assert got[name][r] == pytest.approx(e[name], rel=1e-12, abs=1e-15), name
+        assert got["broken"][r] == e["broken"] and got["year"][r] == p.current_year
+    # a later write extends the file
+    ib.run(1)
+    ib.record_posn()
+    more = ib.num_bond_traj_records()
+    ib.write_bond_trajectories(path)
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        assert f.variables["lon"].shape[0] == len(expect) + more and np.array_equal(f.variables["n1"][:len(expect)], got["n1"])
+    ib.close()

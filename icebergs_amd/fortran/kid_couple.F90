@@ -128,7 +128,7 @@ program kid_couple
     ! straight from the device-resident state
     tp%traj_area_thres = 0. ; tp%traj_area_thres_sntbc = 0. ; tp%traj_area_thres_fl = 1.e9 ; tp%save_all_traj_year = 1.e30
     tp%save_traj_by_class_start_mass_thres_s = 0. ; tp%save_traj_by_class_start_mass_thres_n = 0.
-    tp%save_short_traj = 1 ; tp%save_fl_traj = 1 ; tp%save_nonfl_traj_by_class = 0 ; tp%pad = 0
+    tp%save_short_traj = 1 ; tp%save_fl_traj = 1 ; tp%save_nonfl_traj_by_class = 0 ; tp%save_bond_traj = 0
     call kid_check(kid_set_traj_params(h, tp), h, 'kid_set_traj_params')
     call kid_check(kid_record_posn(h), h, 'kid_record_posn')
     call kid_check(kid_write_trajectories(h, trim(rdir)//'/iceberg_trajectories.nc'//c_null_char), h, 'kid_write_trajectories')

@@ -150,6 +150,29 @@ class Icebergs:
         """write_bond_trajectory, IO2:2106-2331 (needs TrajParams.save_bond_traj and uploaded bonds)"""
         self._check(self.lib.kid_write_bond_trajectories(self.h, str(path).encode()), "kid_write_bond_trajectories")
 
+    # ---- migration between the handles of a decomposed domain (send_bergs_to_other_pes FW:2997-3247) ----
+    def buffer_width(self):
+        w = C.c_int32()
+        self._check(self.lib.kid_buffer_width(self.h, C.byref(w)), "kid_buffer_width")
+        return w.value
+
+    def pack_emigrants(self, direction):
+        """bergs that left through `direction` (types.ENUMS['KID_DIR_E'] ...) as rows of the reference's wire format
+        (pack_berg_into_buffer2 FW:3250-3301); they are gone from the handle afterwards"""
+        w, n = self.buffer_width(), C.c_int64()
+        rc = self.lib.kid_pack_emigrants(self.h, direction, None, 0, C.byref(n))
+        if n.value == 0:
+            self._check(rc, "kid_pack_emigrants")
+            return np.empty((0, w))
+        buf = np.empty((n.value, w))
+        self._check(self.lib.kid_pack_emigrants(self.h, direction, _dp(buf), n.value, C.byref(n)), "kid_pack_emigrants")
+        return buf[:n.value]
+
+    def unpack_immigrants(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        if buf.size:
+            self._check(self.lib.kid_unpack_immigrants(self.h, _dp(buf), buf.shape[0]), "kid_unpack_immigrants")
+
     # ---- restart files (icebergs_fms2io.F90:124-631, 663-1049) ----
     def write_restart(self, directory):
         self._check(self.lib.kid_write_restart(self.h, str(directory).encode()), "kid_write_restart")

@@ -167,6 +167,20 @@ int kid_write_trajectories(kid_handle *h, const char *path);
 int kid_num_bond_traj_records(kid_handle *h, int64_t *n);
 int kid_write_bond_trajectories(kid_handle *h, const char *path);
 
+/* ---- berg migration between the handles of a domain-decomposed model (first slice; send_bergs_to_other_pes
+ * FW:2997-3247).  The handle packs and unpacks the reference's wire format (pack_berg_into_buffer2 FW:3250-3301,
+ * unpack_berg_from_buffer2 FW:3455-3680: buffer_width reals per berg, integers as reals); the caller moves the buffers
+ * (mpp_send / mpp_recv), so a GPU rank can exchange bergs with ranks running the reference.  Call order per step, as FW:3022-3230:
+ * pack E, pack W, send/recv, unpack both, then pack N, pack S, send/recv, unpack both -- after kid_evolve_icebergs /
+ * kid_step_local (a berg that left the computational domain is dead on the device with its post-evolve state kept; packing
+ * consumes it).  kid_pack_emigrants: *n = bergs selected for `dir` (KID_DIR_*); if *n > capacity nothing is packed and
+ * KID_ECAPACITY is returned.  kid_unpack_immigrants appends, resets the *_old fields (FW:3573-3577), finds each berg's cell on
+ * this grid (check_and_find_cell FW:5973-6008) and its xi / yj (FW:3634); a berg no cell of the data domain takes is dropped
+ * and KID_EINVAL returned (the reference's FATAL, FW:3660).  Bonds, mts and dem: KID_EUNSUPPORTED. */
+int kid_buffer_width(kid_handle *h, int32_t *width);
+int kid_pack_emigrants(kid_handle *h, int32_t dir, double *buf, int64_t capacity, int64_t *n);
+int kid_unpack_immigrants(kid_handle *h, const double *buf, int64_t n);
+
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */
 int kid_step_prepare(kid_handle *h, const double *const device_fields[KID_NFORCING]);

@@ -136,6 +136,8 @@ enum {
   KID_B_AXN_FAST, KID_B_AYN_FAST, KID_B_BXN_FAST, KID_B_BYN_FAST, KID_B_ANG_VEL, KID_B_ANG_ACCEL, KID_B_ROT,
   KID_NB_F64
 };
+/* directions of send_bergs_to_other_pes (FW:3022-3130): east and west are exchanged first, then north and south */
+enum { KID_DIR_E = 0, KID_DIR_W, KID_DIR_N, KID_DIR_S };
 /* ---- per-berg int32 fields ---- */
 enum { KID_BI_INE = 0, KID_BI_JNE, KID_BI_START_YEAR, KID_BI_N_BONDS, KID_BI_ALIVE, KID_BI_CONGLOM_ID, KID_NB_I32 };
 

@@ -1587,3 +1587,84 @@ int64_t ko_sizeof(int which) {
   switch (which) { case 0: return (int64_t)sizeof(kid_params); case 1: return (int64_t)sizeof(kid_grid_desc);
                    case 2: return (int64_t)sizeof(kid_berg_soa); case 3: return (int64_t)sizeof(ko_grid); default: return -1; }
 }
+
+/* ---- berg migration between sub-domains: the loops of send_bergs_to_other_pes around its mpp calls ---- */
+
+/* check_and_find_cell, FW:5973-6008: the indices handed in, then the regular-grid guess, then a scan of the data domain */
+int ko_check_and_find_cell(const ko_grid *g, double x, double y, int *oi, int *oj) {
+  const kid_grid_desc *d = &g->d;
+  if (!(*oi - 1 < d->isd || *oi > d->ied || *oj - 1 < d->jsd || *oj > d->jed) && ko_is_point_in_cell(g, x, y, *oi, *oj)) return 1;
+  const double lon0 = GS(g, KID_G_LON, d->isd, d->jsd), lon1 = GS(g, KID_G_LON, d->isd + 1, d->jsd + 1);
+  const double lat0 = GS(g, KID_G_LAT, d->isd, d->jsd), lat1 = GS(g, KID_G_LAT, d->isd + 1, d->jsd + 1);
+  *oi = (int)floor((x - lon0) / (lon1 - lon0)) + d->isd + 1;                              /* FW:5993-5994 */
+  *oj = (int)floor((y - lat0) / (lat1 - lat0)) + d->jsd + 1;
+  if (!(*oi - 1 < d->isd || *oi > d->ied || *oj - 1 < d->jsd || *oj > d->jed) && ko_is_point_in_cell(g, x, y, *oi, *oj)) return 1;
+  *oi = -999; *oj = -999;
+  for (int j = d->jsd + 1; j <= d->jed; ++j)
+    for (int i = d->isd + 1; i <= d->ied; ++i)
+      if (ko_is_point_in_cell(g, x, y, i, j)) { *oi = i; *oj = j; return 1; }
+  return 0;
+}
+
+/* the selection and packing loops of send_bergs_to_other_pes (FW:3022-3048 east/west, FW:3099-3124 north/south) with
+ * pack_berg_into_buffer2 for bergs without bonds (FW:3268-3301: 34 reals, integers as reals).  dir 0 E, 1 W, 2 N, 3 S.
+ * A berg the step deleted for leaving the computational domain (alive == 0, its cell outside) is what the reference
+ * still holds at this point; it is packed and its cell index moved inside (the deletion, FW:3034).  Returns the count. */
+long ko_send_bergs(const ko_grid *g, kid_berg_soa *b, int dir, double *buf) {
+  const kid_grid_desc *d = &g->d;
+  long n = 0;
+  for (long k = 0; k < (long)b->n; ++k) {
+    if (b->f64[KID_B_HALO_BERG] && b->f64[KID_B_HALO_BERG][k] >= 0.5) continue;           /* FW:3027 */
+    const int i = b->i32[KID_BI_INE][k], j = b->i32[KID_BI_JNE][k];
+    const int take = dir == 0 ? i > d->iec : dir == 1 ? i < d->isc : dir == 2 ? j > d->jec : j < d->jsc;
+    if (!take) continue;
+    double *o = buf + (size_t)n * 34;
+    static const int order[34] = {KID_B_LON, KID_B_LAT, KID_B_UVEL, KID_B_VVEL, KID_B_UVEL_PREV, KID_B_VVEL_PREV, KID_B_XI, KID_B_YJ,
+      KID_B_START_LON, KID_B_START_LAT, -1, KID_B_START_DAY, KID_B_START_MASS, KID_B_MASS, KID_B_THICKNESS, KID_B_WIDTH, KID_B_LENGTH,
+      KID_B_FL_K, KID_B_MASS_SCALING, KID_B_MASS_OF_BITS, KID_B_MASS_OF_FL_BITS, KID_B_MASS_OF_FL_BERGY_BITS, KID_B_HEAT_DENSITY, -2, -3,
+      KID_B_AXN, KID_B_AYN, KID_B_BXN, KID_B_BYN, KID_B_HALO_BERG, KID_B_STATIC_BERG, -4, -5, KID_B_OD};
+    for (int q = 0; q < 34; ++q) {
+      const int f = order[q];
+      if (f >= 0) o[q] = b->f64[f] ? b->f64[f][k] : 0.;
+      else if (f == -1) o[q] = (double)b->i32[KID_BI_START_YEAR][k];
+      else if (f == -2) o[q] = (double)i;
+      else if (f == -3) o[q] = (double)j;
+      else if (f == -4) o[q] = (double)(int32_t)(b->id[k] >> 32);                         /* split_id, FW:3297 */
+      else o[q] = (double)(int32_t)(b->id[k] & 0xffffffffll);
+    }
+    b->i32[KID_BI_ALIVE][k] = 0; b->i32[KID_BI_INE][k] = d->isc; b->i32[KID_BI_JNE][k] = d->jsc;
+    ++n;
+  }
+  return n;
+}
+
+/* unpack_berg_from_buffer2 without bonds (FW:3503-3541, 3573-3577, 3626-3637) into rows b->n .. b->n + m - 1 of arrays
+ * that have the room; returns the number of bergs no cell took (FATAL in the reference, FW:3660; dropped here) */
+long ko_unpack_bergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b, const double *buf, long m) {
+  long lost = 0;
+  for (long q = 0; q < m; ++q) {
+    const double *r = buf + (size_t)q * 34;
+    const long k = (long)b->n;
+    for (int f = 0; f < KID_NB_F64; ++f) if (b->f64[f]) b->f64[f][k] = 0.;
+    for (int f = 0; f < KID_NB_I32; ++f) if (b->i32[f]) b->i32[f][k] = 0;
+    PUT(b, KID_B_LON, k, r[0]); PUT(b, KID_B_LAT, k, r[1]); PUT(b, KID_B_UVEL, k, r[2]); PUT(b, KID_B_VVEL, k, r[3]);
+    PUT(b, KID_B_UVEL_PREV, k, r[4]); PUT(b, KID_B_VVEL_PREV, k, r[5]); PUT(b, KID_B_XI, k, r[6]); PUT(b, KID_B_YJ, k, r[7]);
+    PUT(b, KID_B_START_LON, k, r[8]); PUT(b, KID_B_START_LAT, k, r[9]); b->i32[KID_BI_START_YEAR][k] = (int)lrint(r[10]);
+    PUT(b, KID_B_START_DAY, k, r[11]); PUT(b, KID_B_START_MASS, k, r[12]); PUT(b, KID_B_MASS, k, r[13]); PUT(b, KID_B_THICKNESS, k, r[14]);
+    PUT(b, KID_B_WIDTH, k, r[15]); PUT(b, KID_B_LENGTH, k, r[16]); PUT(b, KID_B_FL_K, k, r[17]); PUT(b, KID_B_MASS_SCALING, k, r[18]);
+    PUT(b, KID_B_MASS_OF_BITS, k, r[19]); PUT(b, KID_B_MASS_OF_FL_BITS, k, r[20]); PUT(b, KID_B_MASS_OF_FL_BERGY_BITS, k, r[21]);
+    PUT(b, KID_B_HEAT_DENSITY, k, r[22]);
+    PUT(b, KID_B_AXN, k, r[25]); PUT(b, KID_B_AYN, k, r[26]); PUT(b, KID_B_BXN, k, r[27]); PUT(b, KID_B_BYN, k, r[28]);
+    PUT(b, KID_B_HALO_BERG, k, r[29]); PUT(b, KID_B_STATIC_BERG, k, r[30]); PUT(b, KID_B_OD, k, r[33]);
+    b->id[k] = (int64_t)(((uint64_t)(uint32_t)(int32_t)lrint(r[31]) << 32) | (uint64_t)(uint32_t)(int32_t)lrint(r[32]));   /* id_from_2_ints */
+    PUT(b, KID_B_UVEL_OLD, k, r[2]); PUT(b, KID_B_VVEL_OLD, k, r[3]); PUT(b, KID_B_LON_OLD, k, r[0]); PUT(b, KID_B_LAT_OLD, k, r[1]);   /* FW:3573-3577 */
+    int i = (int)lrint(r[23]), j = (int)lrint(r[24]);
+    if (!ko_check_and_find_cell(g, r[0], r[1], &i, &j)) { ++lost; continue; }             /* FW:3628; find_cell_wide repeats the same scan */
+    double xi, yj; int perr = 0;
+    (void)ko_pos_within_cell(g, p, r[0], r[1], i, j, &xi, &yj, &perr);                    /* FW:3634 */
+    b->i32[KID_BI_INE][k] = i; b->i32[KID_BI_JNE][k] = j; PUT(b, KID_B_XI, k, xi); PUT(b, KID_B_YJ, k, yj);
+    b->i32[KID_BI_ALIVE][k] = 1;
+    b->n += 1;
+  }
+  return lost;
+}

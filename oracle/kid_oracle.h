@@ -73,6 +73,10 @@ void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t
                  double *acc, double *out, double *scalars);
 /* reference traversal order: permutation sorted by (jne, ine, inorder-key) */
 void ko_reference_order(const kid_berg_soa *b, int64_t *perm);
+/* berg migration between sub-domains: send_bergs_to_other_pes FW:2997-3247, pack / unpack FW:3250-3301, 3455-3680 */
+int  ko_check_and_find_cell(const ko_grid *g, double x, double y, int *oi, int *oj);
+long ko_send_bergs(const ko_grid *g, kid_berg_soa *b, int dir, double *buf);
+long ko_unpack_bergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b, const double *buf, long m);
 
 /* multiple time stepping / DEM (oracle/kid_oracle_mts.c) */
 void ko_evolve_icebergs_mts(const ko_grid *g, const kid_params *p, kid_berg_soa *b, kid_bond_soa *bd, double *scalars);

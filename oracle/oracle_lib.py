@@ -91,6 +91,10 @@ def load():
     lib.ko_run_step.restype = None
     lib.ko_run_step.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64,
                                 C.POINTER(d), C.POINTER(d), C.POINTER(d)]
+    lib.ko_send_bergs.restype = C.c_long
+    lib.ko_send_bergs.argtypes = [C.POINTER(KoGrid), C.POINTER(T.BergSoA), C.c_int, C.POINTER(d)]
+    lib.ko_unpack_bergs.restype = C.c_long
+    lib.ko_unpack_bergs.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.c_long]
     lib.ko_reference_order.restype = None
     lib.ko_reference_order.argtypes = [C.POINTER(T.BergSoA), C.POINTER(C.c_int64)]
     return lib
@@ -232,6 +236,22 @@ class Oracle:
             self.lib.ko_run_step_interactive(C.byref(self.kg), C.byref(self.params), C.byref(s), C.byref(bs), first,
                                              _dp(self.acc), _dp(self.out), _dp(self.scalars))
         return bergs, bonds
+
+    def send_bergs(self, bergs, direction):
+        """the packing loop of send_bergs_to_other_pes for one direction (0 E, 1 W, 2 N, 3 S): rows of 34 reals"""
+        s = self.soa(bergs)
+        buf = np.zeros((max(int(s.n), 1), 34))
+        n = self.lib.ko_send_bergs(C.byref(self.kg), C.byref(s), int(direction), _dp(buf))
+        return buf[:n].copy()
+
+    def unpack_bergs(self, bergs, buf):
+        """unpack_berg_from_buffer2 into the spare rows of `bergs` (bergs["_n"] live rows); returns the bergs no cell took"""
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        s = self.soa(bergs)
+        assert int(s.n) + len(buf) <= len(bergs["lon"]), "no room for the arrivals"
+        lost = self.lib.ko_unpack_bergs(C.byref(self.kg), C.byref(self.params), C.byref(s), _dp(buf), len(buf)) if len(buf) else 0
+        bergs["_n"] = int(s.n)
+        return int(lost)
 
     def step_local(self, bergs):
         s = self.soa(bergs)

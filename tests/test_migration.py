@@ -157,3 +157,103 @@ def test_wire_format_and_refusals():
         ib.pack_emigrants(E)
     ib.close()
     east.close()
+
+
+def test_tiles_against_the_oracle():
+    """the same 2 x 2 exchange stepped by the CPU oracle (oracle/kid_oracle.c: ko_send_bergs, ko_unpack_bergs around
+    ko_evolve_icebergs / ko_thermodynamics): per tile the same bergs with the same state, and the same records on the wire"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from oracle_lib import Oracle, _dp
+    from icebergs_amd.framework import Icebergs
+    ntx = nty = 2
+    whole = _grid(None, None, ntx, nty)
+    p = S.default_params()
+    p.dt, p.old_interp_flds_order = 1800.0, 1
+    n, cap = 3000, 3600
+    b = S.place_bergs(whole, n, 23, (2, NI * ntx - 1), (2, NJ * nty - 1))
+    tiles, orc, ob = {}, {}, {}
+    for tx in range(ntx):
+        for ty in range(nty):
+            g = _grid(tx, ty, ntx, nty)
+            sel = ((b["ine"] - 1) // NI == tx) & ((b["jne"] - 1) // NJ == ty)
+            bt = {k: (v[sel].copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+            bt["ine"] = bt["ine"] - tx * NI
+            bt["jne"] = bt["jne"] - ty * NJ
+            ib = Icebergs(g, p, capacity=cap)
+            ib.upload_bergs(bt)
+            tiles[(tx, ty)] = ib
+            big = S.empty_bergs(cap)
+            m = int(sel.sum())
+            for k, v in bt.items():
+                if isinstance(v, np.ndarray):
+                    big[k][:m] = v
+            big["_n"] = m
+            ob[(tx, ty)] = big
+            orc[(tx, ty)] = Oracle(g, p)
+
+    def oracle_step():
+        wire = []
+        for key, o in orc.items():
+            o.acc[:] = 0.0
+            s = o.soa(ob[key])
+            o.lib.ko_evolve_icebergs(C.byref(o.kg), C.byref(o.params), C.byref(s), _dp(o.scalars))
+        for first, second, shift in ((0, 1, (1, 0)), (2, 3, (0, 1))):
+            out = {key: (o.send_bergs(ob[key], first), o.send_bergs(ob[key], second)) for key, o in orc.items()}
+            for (tx, ty), o in orc.items():
+                lo, hi = (tx - shift[0], ty - shift[1]), (tx + shift[0], ty + shift[1])
+                if lo in out:
+                    assert o.unpack_bergs(ob[(tx, ty)], out[lo][0]) == 0
+                if hi in out:
+                    assert o.unpack_bergs(ob[(tx, ty)], out[hi][1]) == 0
+            wire.append(out)
+        for key, o in orc.items():
+            s = o.soa(ob[key])
+            o.lib.ko_thermodynamics(C.byref(o.kg), C.byref(o.params), C.byref(s), _dp(o.acc), _dp(o.scalars))
+        return wire
+
+    def hip_step():
+        wire = []
+
+        def exchange(ibs):
+            for first, second, shift in ((E, W, (1, 0)), (N, So, (0, 1))):
+                out = {key: (ib.pack_emigrants(first), ib.pack_emigrants(second)) for key, ib in ibs.items()}
+                for (tx, ty), ib in ibs.items():
+                    lo, hi = (tx - shift[0], ty - shift[1]), (tx + shift[0], ty + shift[1])
+                    if lo in out:
+                        ib.unpack_immigrants(out[lo][0])
+                    if hi in out:
+                        ib.unpack_immigrants(out[hi][1])
+                wire.append(out)
+            return 0
+        _phases(tiles, exchange)
+        return wire
+
+    crossings = 0
+    for step in range(16):
+        wo, wh = oracle_step(), hip_step()
+        for po, ph in zip(wo, wh):                               # the records on the wire, pass by pass, tile by tile
+            for key in po:
+                for a, c in zip(po[key], ph[key]):
+                    assert a.shape == c.shape, (step, key, a.shape, c.shape)
+                    if len(a):
+                        ida = a[:, 31] * 2.0 ** 32 + a[:, 32]
+                        idc = c[:, 31] * 2.0 ** 32 + c[:, 32]
+                        a, c = a[np.argsort(ida)], c[np.argsort(idc)]
+                        assert np.array_equal(a[:, [10, 23, 24, 31, 32]], c[:, [10, 23, 24, 31, 32]])      # the integers
+                        assert np.allclose(a, c, rtol=1e-9, atol=1e-12), float(np.abs(a - c).max())
+                        crossings += len(a)
+    assert crossings > 100, crossings
+    for key, ib in tiles.items():
+        hb, o = ib.download_bergs(), ob[key]
+        m = o["_n"]
+        ha, oa = hb["alive"] != 0, o["alive"][:m] != 0
+        o1, o2 = np.argsort(hb["id"][ha]), np.argsort(o["id"][:m][oa])
+        assert np.array_equal(hb["id"][ha][o1], o["id"][:m][oa][o2]), key
+        for f in ("ine", "jne", "start_year"):
+            assert np.array_equal(hb[f][ha][o1], o[f][:m][oa][o2]), (key, f)
+        for f in ("lon", "lat", "uvel", "vvel", "xi", "yj", "mass", "thickness", "width", "length", "axn", "ayn", "bxn", "byn", "mass_of_bits", "heat_density",
+                  "lon_old", "uvel_old"):
+            x, y = hb[f][ha][o1], o[f][:m][oa][o2]
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-11), (key, f, float(np.abs(x - y).max()))
+        ib.close()

@@ -590,7 +590,7 @@ struct kid_handle {
   // trajectories (kid_traj.inc): one buffer per sampled field, grown on demand
   bool traj_on = false; kid_traj_params traj_params{}; double *d_traj_f[64] = {}; double *d_traj_day = nullptr; int64_t *d_traj_id = nullptr;
   int32_t *d_traj_year = nullptr, *d_traj_nbonds = nullptr; unsigned long long *d_traj_cursor = nullptr; long long traj_capacity = 0, traj_count_bound = 0; int traj_nf = 0;
-  double *d_mig_buf = nullptr; long long mig_capacity = 0;   // staging for kid_pack_emigrants
+  double *d_mig_buf = nullptr; long long mig_capacity = 0; unsigned long long *mig_word = nullptr;   // pinned staging of kid_pack_emigrants / kid_unpack_immigrants
   double *d_btraj_f[16] = {}; int64_t *d_btraj_id[2] = {}; int32_t *d_btraj_i[2] = {}; long long btraj_capacity = 0, btraj_count_bound = 0;   // bond samples
   double *d_spread_mass_old = nullptr;   // grd%spread_mass_old (find_melt_using_spread_mass, IB:5495-5497)
   bool have_static = false, have_forcing = false, have_planes = false;  // have_planes: d_forcing holds all eleven planes
@@ -798,7 +798,8 @@ int kid_destroy(kid_handle *h) {
   if (h->d_traj_year) (void)hipFree(h->d_traj_year);
   if (h->d_traj_nbonds) (void)hipFree(h->d_traj_nbonds);
   if (h->d_traj_cursor) (void)hipFree(h->d_traj_cursor);
-  if (h->d_mig_buf) (void)hipFree(h->d_mig_buf);
+  if (h->d_mig_buf) (void)hipHostFree(h->d_mig_buf);
+  if (h->mig_word) (void)hipHostFree(h->mig_word);
   for (auto &q : h->d_btraj_f) if (q) (void)hipFree(q);
   for (int f = 0; f < 2; ++f) { if (h->d_btraj_id[f]) (void)hipFree(h->d_btraj_id[f]); if (h->d_btraj_i[f]) (void)hipFree(h->d_btraj_i[f]); }
   if (h->evR) (void)hipEventDestroy(h->evR);

@@ -159,14 +159,15 @@ class Icebergs:
     def pack_emigrants(self, direction):
         """bergs that left through `direction` (types.ENUMS['KID_DIR_E'] ...) as rows of the reference's wire format
         (pack_berg_into_buffer2 FW:3250-3301); they are gone from the handle afterwards"""
-        w, n = self.buffer_width(), C.c_int64()
-        rc = self.lib.kid_pack_emigrants(self.h, direction, None, 0, C.byref(n))
-        if n.value == 0:
-            self._check(rc, "kid_pack_emigrants")
-            return np.empty((0, w))
-        buf = np.empty((n.value, w))
-        self._check(self.lib.kid_pack_emigrants(self.h, direction, _dp(buf), n.value, C.byref(n)), "kid_pack_emigrants")
-        return buf[:n.value]
+        n = C.c_int64()
+        if getattr(self, "_mig_buf", None) is None:
+            self._mig_buf = np.empty((4096, self.buffer_width()))
+        rc = self.lib.kid_pack_emigrants(self.h, direction, _dp(self._mig_buf), self._mig_buf.shape[0], C.byref(n))
+        if rc == -4 and n.value > self._mig_buf.shape[0]:        # KID_ECAPACITY: nothing was packed, n says how many wait
+            self._mig_buf = np.empty((2 * n.value, self._mig_buf.shape[1]))
+            rc = self.lib.kid_pack_emigrants(self.h, direction, _dp(self._mig_buf), self._mig_buf.shape[0], C.byref(n))
+        self._check(rc, "kid_pack_emigrants")
+        return self._mig_buf[:n.value].copy()
 
     def unpack_immigrants(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.float64)

@@ -734,7 +734,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_lane, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipMemset(h->d_lane, 0, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipEventCreateWithFlags(&h->evC, hipEventDisableTiming)); KID_HIP(h, hipEventCreateWithFlags(&h->evP, hipEventDisableTiming));
-  KID_HIP(h, hipMalloc(&h->d_count, sizeof(unsigned long long)));
+  KID_HIP(h, hipMalloc(&h->d_count, 4 * sizeof(unsigned long long)));
   KID_HIP(h, hipMalloc(&h->d_iceberg_counter, h->ncell * sizeof(int32_t)));
   KID_HIP(h, hipMemset(h->d_iceberg_counter, 0, h->ncell * sizeof(int32_t)));
   KID_HIP(h, hipMalloc(&h->d_fl_cursor, sizeof(int)));

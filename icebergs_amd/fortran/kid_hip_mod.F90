@@ -23,7 +23,7 @@ module kid_hip_mod
   public :: kid_calving_params, kid_calving_in, kid_set_calving_params, kid_set_calving_state, kid_get_calving_state
   public :: kid_calving, kid_get_calving, KID_NCALV_SCALARS, KID_NCLASSES
   public :: kid_write_restart, kid_read_restart
-  public :: kid_buffer_width, kid_pack_emigrants, kid_unpack_immigrants, KID_DIR_E, KID_DIR_W, KID_DIR_N, KID_DIR_S
+  public :: kid_buffer_width, kid_pack_emigrants, kid_unpack_immigrants, kid_pack_emigrants_pair, kid_unpack_immigrants_pair, KID_DIR_E, KID_DIR_W, KID_DIR_N, KID_DIR_S
   public :: kid_traj_params, kid_set_traj_params, kid_record_posn, kid_write_trajectories, kid_write_bond_trajectories
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
@@ -148,6 +148,20 @@ module kid_hip_mod
       real(c_double), intent(out) :: buf(*)          ! obuffer%data(buffer_width, capacity), FW:3250
       integer(c_int64_t), value :: capacity
       integer(c_int64_t), intent(out) :: n
+    end function
+    integer(c_int) function kid_pack_emigrants_pair(h, axis, buf_a, capacity_a, n_a, buf_b, capacity_b, n_b) bind(C, name='kid_pack_emigrants_pair')
+      import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: axis              ! 0: east (a) + west (b), 1: north (a) + south (b)
+      real(c_double), intent(out) :: buf_a(*), buf_b(*)
+      integer(c_int64_t), value :: capacity_a, capacity_b
+      integer(c_int64_t), intent(out) :: n_a, n_b
+    end function
+    integer(c_int) function kid_unpack_immigrants_pair(h, buf_a, n_a, buf_b, n_b) bind(C, name='kid_unpack_immigrants_pair')
+      import :: c_int, c_ptr, c_int64_t, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: buf_a(*), buf_b(*)
+      integer(c_int64_t), value :: n_a, n_b
     end function
     integer(c_int) function kid_unpack_immigrants(h, buf, n) bind(C, name='kid_unpack_immigrants')
       import :: c_int, c_ptr, c_int64_t, c_double

@@ -169,6 +169,26 @@ class Icebergs:
         self._check(rc, "kid_pack_emigrants")
         return self._mig_buf[:n.value].copy()
 
+    def pack_emigrants_pair(self, axis):
+        """east + west (axis 0) or north + south (axis 1) in one launch; returns the two record arrays"""
+        na, nb = C.c_int64(), C.c_int64()
+        if getattr(self, "_mig_buf2", None) is None:
+            self._mig_buf2 = [np.empty((4096, self.buffer_width())) for _ in range(2)]
+        for attempt in range(2):
+            a, b = self._mig_buf2
+            rc = self.lib.kid_pack_emigrants_pair(self.h, axis, _dp(a), a.shape[0], C.byref(na), _dp(b), b.shape[0], C.byref(nb))
+            if rc != -4 or attempt:
+                break
+            self._mig_buf2 = [np.empty((max(2 * n.value, x.shape[0]), x.shape[1])) for n, x in ((na, a), (nb, b))]   # KID_ECAPACITY: nothing was packed
+        self._check(rc, "kid_pack_emigrants_pair")
+        return self._mig_buf2[0][:na.value].copy(), self._mig_buf2[1][:nb.value].copy()
+
+    def unpack_immigrants_pair(self, buf_a, buf_b):
+        a, b = (np.ascontiguousarray(x, dtype=np.float64) for x in (buf_a, buf_b))
+        if a.size or b.size:
+            self._check(self.lib.kid_unpack_immigrants_pair(self.h, _dp(a) if a.size else None, a.shape[0] if a.size else 0,
+                                                            _dp(b) if b.size else None, b.shape[0] if b.size else 0), "kid_unpack_immigrants_pair")
+
     def unpack_immigrants(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.float64)
         if buf.size:

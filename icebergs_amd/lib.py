@@ -25,7 +25,7 @@ SYMBOLS = [
     "kid_restart_write_bergs", "kid_restart_count_bergs", "kid_restart_read_bergs", "kid_restart_write_bonds", "kid_restart_read_bonds", "kid_write_restart", "kid_read_restart",
     "kid_set_traj_params", "kid_record_posn", "kid_num_traj_records", "kid_write_trajectories",
     "kid_num_bond_traj_records", "kid_write_bond_trajectories",
-    "kid_buffer_width", "kid_pack_emigrants", "kid_unpack_immigrants",
+    "kid_buffer_width", "kid_pack_emigrants", "kid_unpack_immigrants", "kid_pack_emigrants_pair", "kid_unpack_immigrants_pair",
 ]
 
 
@@ -90,6 +90,8 @@ def load():
     lib.kid_buffer_width.argtypes = [H, C.POINTER(C.c_int32)]
     lib.kid_pack_emigrants.argtypes = [H, C.c_int32, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]
     lib.kid_unpack_immigrants.argtypes = [H, C.POINTER(C.c_double), C.c_int64]
+    lib.kid_pack_emigrants_pair.argtypes = [H, C.c_int32, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]
+    lib.kid_unpack_immigrants_pair.argtypes = [H, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int64]
     lib.kid_read_restart.argtypes = [H, C.c_char_p]
     lib.kid_upload_bergs.argtypes = [H, C.POINTER(T.BergSoA)]
     lib.kid_step_prepare.argtypes = [H, C.POINTER(C.c_void_p)]

@@ -180,6 +180,11 @@ int kid_write_bond_trajectories(kid_handle *h, const char *path);
 int kid_buffer_width(kid_handle *h, int32_t *width);
 int kid_pack_emigrants(kid_handle *h, int32_t dir, double *buf, int64_t capacity, int64_t *n);
 int kid_unpack_immigrants(kid_handle *h, const double *buf, int64_t n);
+/* the two directions of one exchange pass in one launch and one host read each way: axis 0 = east (a) and west (b), axis 1 =
+ * north (a) and south (b); the pair unpack appends the rows of buf_a, then those of buf_b (the order of the reference's two
+ * unpack loops, FW:3064-3097).  Same results as the single calls. */
+int kid_pack_emigrants_pair(kid_handle *h, int32_t axis, double *buf_a, int64_t capacity_a, int64_t *n_a, double *buf_b, int64_t capacity_b, int64_t *n_b);
+int kid_unpack_immigrants_pair(kid_handle *h, const double *buf_a, int64_t n_a, const double *buf_b, int64_t n_b);
 
 /* kid_set_forcing_device + kid_zero_accumulators for the step about to start, as one per-cell launch (fields == NULL
  * keeps the current forcing and only zeroes); the following kid_step_local does not zero again. */

@@ -48,23 +48,30 @@ def _phases(ibs, exchange):
     return sent
 
 
-def _exchange(ntx, nty):
+def _exchange(ntx, nty, pair=False):
     def run(ibs):
         sent = 0
-        for first, second, shift in ((E, W, (1, 0)), (N, So, (0, 1))):
-            out = {key: (ib.pack_emigrants(first), ib.pack_emigrants(second)) for key, ib in ibs.items()}
+        empty = np.empty((0, 34))
+        for axis, (first, second, shift) in enumerate(((E, W, (1, 0)), (N, So, (0, 1)))):
+            if pair:
+                out = {key: ib.pack_emigrants_pair(axis) for key, ib in ibs.items()}
+            else:
+                out = {key: (ib.pack_emigrants(first), ib.pack_emigrants(second)) for key, ib in ibs.items()}
             for (tx, ty), ib in ibs.items():
                 lo, hi = (tx - shift[0], ty - shift[1]), (tx + shift[0], ty + shift[1])
-                if lo in out:                                  # from the west / south neighbour first (FW:3064, 3160)
-                    ib.unpack_immigrants(out[lo][0]); sent += len(out[lo][0])
-                if hi in out:
-                    ib.unpack_immigrants(out[hi][1]); sent += len(out[hi][1])
+                from_lo, from_hi = out[lo][0] if lo in out else empty, out[hi][1] if hi in out else empty
+                sent += len(from_lo) + len(from_hi)
+                if pair:
+                    ib.unpack_immigrants_pair(from_lo, from_hi)
+                else:                                          # from the west / south neighbour first (FW:3064, 3160)
+                    ib.unpack_immigrants(from_lo)
+                    ib.unpack_immigrants(from_hi)
         return sent
     return run
 
 
-@pytest.mark.parametrize("old_order", [1, 0])
-def test_two_by_two_tiles_match_the_undivided_grid(old_order):
+@pytest.mark.parametrize("old_order,pair", [(1, False), (0, False), (1, True)])
+def test_two_by_two_tiles_match_the_undivided_grid(old_order, pair):
     from icebergs_amd.framework import Icebergs
     ntx = nty = 2
     whole = _grid(None, None, ntx, nty)
@@ -89,7 +96,7 @@ def test_two_by_two_tiles_match_the_undivided_grid(old_order):
     moved = 0
     for _ in range(40):
         _phases({"whole": ref}, lambda ibs: 0)
-        moved += _phases(tiles, _exchange(ntx, nty))
+        moved += _phases(tiles, _exchange(ntx, nty, pair))
     assert moved > 500, moved                                   # bergs did cross tile boundaries, corners included
     rb = ref.download_bergs()
     ra = rb["alive"] != 0

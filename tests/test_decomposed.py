@@ -29,12 +29,36 @@ def _grid(tx, ntx):
     return g
 
 
-def _population(ntx, n):
+RES = 2000.0    # the periodic Cartesian channel: cells of 2 km, Lx = the whole box
+
+
+def _channel(tx, ntx):
+    """a zonally periodic channel (the stand-alone driver's Cartesian grid with Lx = its width), or one tile of it; the flow
+    is periodic in x, so a tile's halo across the seam holds what its neighbour's cells hold"""
     from icebergs_amd import synthetic as S
-    whole = _grid(None, ntx)
+    Lx = ntx * NI * RES
+    g = S.cartesian_grid(ni=NI * ntx if tx is None else NI, nj=NJ, gridres=RES, Lx=Lx)
+    st, f = g["static"], g["forcing"]
+    if tx:
+        st["lon"] += tx * NI * RES
+        st["lonc"] += tx * NI * RES
+    w = 2.0 * np.pi / Lx
+    f["uo"][:] = 0.6 + 0.2 * np.sin(w * st["lon"])
+    f["vo"][:] = 0.05 * np.cos(2.0 * w * st["lon"]) * np.sin(np.pi * st["lat"] / (NJ * RES))
+    f["ua"][:] = 4.0
+    f["sst"][:] = 1.0 + np.sin(w * st["lonc"])
+    f["sss"][:] = -1.0
+    return g
+
+
+def _population(ntx, n, cyclic=False):
+    from icebergs_amd import synthetic as S
+    whole = _channel(None, ntx) if cyclic else _grid(None, ntx)
     p = S.default_params()
     p.dt = 1800.0
-    return whole, p, S.place_bergs(whole, n, 3, (2, ntx * NI - 1), (2, NJ - 1))
+    if cyclic:
+        p.lat_ref, p.use_f_plane, p.periodic_reentry = -70.0, 1, 1      # the whole-grid run treats its seam as the boundary between two PEs
+    return whole, p, S.place_bergs(whole, n, 3, (2, ntx * NI - 1), (3, NJ - 2))
 
 
 class OracleTile:
@@ -93,13 +117,15 @@ class HipRun:
         return {k: b[k][a] for k in FIELDS + ("id",)}
 
 
-def _worker(rank, world, port, backend, nbergs, nsteps, out_dir):
+def _worker(rank, world, port, backend, nbergs, nsteps, out_dir, cyclic=False):
     from icebergs_amd import synthetic as S
     from icebergs_amd.decomposed import TileExchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    whole, p, b = _population(world, nbergs)
+    whole, p, b = _population(world, nbergs, cyclic)
+    if cyclic:
+        p.periodic_reentry = 0            # on a tile the seam is a real boundary between ranks
     sel = (b["ine"] - 1) // NI == rank
     cap = nbergs
     big = S.empty_bergs(cap)
@@ -109,9 +135,10 @@ def _worker(rank, world, port, backend, nbergs, nsteps, out_dir):
             big[k][:m] = v[sel]
     big["ine"][:m] -= rank * NI
     big["_n"] = m
-    tile = OracleTile(_grid(rank, world), p, big) if backend == "oracle" else HipRun(_grid(rank, world), p, big, cap)
-    ex = TileExchange(world, 1, dist)
-    assert ex.neighbour(1, 0) == (rank + 1 if rank + 1 < world else None) and ex.neighbour(0, 1) is None
+    g = _channel(rank, world) if cyclic else _grid(rank, world)
+    tile = OracleTile(g, p, big) if backend == "oracle" else HipRun(g, p, big, cap)
+    ex = TileExchange(world, 1, dist, cyclic_x=cyclic)
+    assert ex.neighbour(1, 0) == ((rank + 1) % world if cyclic else (rank + 1 if rank + 1 < world else None)) and ex.neighbour(0, 1) is None
     for _ in range(nsteps):
         tile.evolve()
         ex.exchange(tile)
@@ -121,9 +148,9 @@ def _worker(rank, world, port, backend, nbergs, nsteps, out_dir):
     dist.destroy_process_group()
 
 
-def _check(tmp_path, world, nbergs, nsteps, tol):
+def _check(tmp_path, world, nbergs, nsteps, tol, cyclic=False):
     import oracle_lib
-    whole, p, b = _population(world, nbergs)
+    whole, p, b = _population(world, nbergs, cyclic)
     ref = OracleTile(whole, p, b)
     for _ in range(nsteps):
         ref.evolve()
@@ -133,7 +160,7 @@ def _check(tmp_path, world, nbergs, nsteps, tol):
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert sum(int(q["sent"]) for q in parts) == sum(int(q["received"]) for q in parts) > 20
     ids = np.concatenate([q["id"] for q in parts])
-    assert len(np.unique(ids)) == len(ids) and set(ids) == set(want["id"]) and len(ids) < nbergs
+    assert len(np.unique(ids)) == len(ids) and set(ids) == set(want["id"]) and (cyclic or len(ids) < nbergs)
     o1, o2 = np.argsort(want["id"]), np.argsort(ids)
     for f in ("lon", "lat", "uvel", "vvel", "mass", "thickness"):
         got = np.concatenate([q[f] for q in parts])
@@ -146,6 +173,17 @@ def test_two_ranks_gloo_oracle_tiles(tmp_path):
     port = 29700 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, "oracle", 400, 30, str(tmp_path)), nprocs=2, join=True)
     _check(tmp_path, 2, 400, 30, 1e-12)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cyclic_channel_gloo_oracle_tiles(tmp_path, world):
+    """a zonally periodic channel cut into 2 (east and west neighbour are the same rank) or 3 tiles: bergs go round and round;
+    against the undivided channel with periodic_reentry"""
+    import oracle_lib
+    oracle_lib.build()
+    port = 30100 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, "oracle", 300, 60, str(tmp_path), True), nprocs=world, join=True)
+    _check(tmp_path, world, 300, 60, 1e-11, cyclic=True)
 
 
 def test_same_peer_swap_and_layout():
@@ -163,8 +201,10 @@ def test_same_peer_swap_and_layout():
 
 
 @pytest.mark.gpu
-def test_two_ranks_hip_tiles_on_one_gpu(tmp_path):
-    """the same two-rank run with the HIP handles (both ranks on GPU 0, gloo for the messages), against the undivided oracle"""
-    port = 29900 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, "hip", 400, 30, str(tmp_path)), nprocs=2, join=True)
-    _check(tmp_path, 2, 400, 30, 1e-9)
+@pytest.mark.parametrize("cyclic", [False, True])
+def test_two_ranks_hip_tiles_on_one_gpu(tmp_path, cyclic):
+    """the same two-rank runs with the HIP handles (both ranks on GPU 0, gloo for the messages), against the undivided oracle"""
+    port = 29900 + (os.getpid() % 2000) + int(cyclic)
+    nbergs, nsteps = (300, 60) if cyclic else (400, 30)
+    mp.spawn(_worker, args=(2, port, "hip", nbergs, nsteps, str(tmp_path), cyclic), nprocs=2, join=True)
+    _check(tmp_path, 2, nbergs, nsteps, 1e-9, cyclic=cyclic)

@@ -264,3 +264,31 @@ def test_tiles_against_the_oracle():
             x, y = hb[f][ha][o1], o[f][:m][oa][o2]
             assert np.allclose(x, y, rtol=1e-9, atol=1e-11), (key, f, float(np.abs(x - y).max()))
         ib.close()
+
+
+def test_pack_capacity_contract():
+    """a buffer that is too small: KID_ECAPACITY, *n = how many wait, nothing consumed; the same call with room then gets all
+    of them, once; the pair call keeps the two directions apart"""
+    from icebergs_amd.framework import Icebergs, _dp
+    g = _grid(0, 0, 2, 2)
+    p = S.default_params()
+    b = S.place_bergs(g, 12, 9, (3, 8), (3, 8))
+    b["ine"][:5] = NI + 1                                       # five wait for the east, three for the west
+    b["ine"][5:8] = 0
+    ib = Icebergs(g, p, capacity=16)
+    ib.upload_bergs(b)
+    n = C.c_int64()
+    small = np.zeros((2, 34))
+    assert ib.lib.kid_pack_emigrants(ib.h, E, _dp(small), 2, C.byref(n)) == -4 and n.value == 5 and not small.any()
+    assert ib.num_bergs()[1] == 12                               # nobody was deleted
+    na, nb = C.c_int64(), C.c_int64()
+    ea, we = np.zeros((8, 34)), np.zeros((2, 34))
+    assert ib.lib.kid_pack_emigrants_pair(ib.h, 0, _dp(ea), 8, C.byref(na), _dp(we), 2, C.byref(nb)) == -4 and (na.value, nb.value) == (5, 3)
+    assert ib.num_bergs()[1] == 12
+    we = np.zeros((4, 34))
+    assert ib.lib.kid_pack_emigrants_pair(ib.h, 0, _dp(ea), 8, C.byref(na), _dp(we), 4, C.byref(nb)) == 0 and (na.value, nb.value) == (5, 3)
+    assert sorted(ea[:5, 32].astype(int)) == sorted(int(i) & 0xffffffff for i in b["id"][:5])
+    assert sorted(we[:3, 32].astype(int)) == sorted(int(i) & 0xffffffff for i in b["id"][5:8])
+    assert np.all(ea[:5, 23] == NI + 1) and np.all(we[:3, 23] == 0)
+    assert ib.num_bergs()[1] == 4 and len(ib.pack_emigrants(E)) == 0 and len(ib.pack_emigrants(W)) == 0
+    ib.close()

@@ -137,6 +137,19 @@ program kid_couple
   call kid_check(kid_num_bergs(h, n_slots, n_alive), h, 'kid_num_bergs')
   soa%n = n_slots
   call kid_check(kid_download_bergs(h, soa), h, 'kid_download_bergs')
+  ! the packing loops of send_bergs_to_other_pes for east + west (FW:3022-3048) through the module, on the state just
+  ! downloaded: what a decomposed model would hand to mpp_send
+  block
+    integer(c_int32_t) :: bw
+    integer(c_int64_t) :: n_e, n_w, rows
+    real(c_double), allocatable :: obuf_e(:,:), obuf_w(:,:)
+    call kid_check(kid_buffer_width(h, bw), h, 'kid_buffer_width')
+    rows = max(n_slots, 1_c_int64_t)
+    allocate(obuf_e(bw, rows), obuf_w(bw, rows))
+    call kid_check(kid_pack_emigrants_pair(h, 0_c_int32_t, obuf_e, rows, n_e, obuf_w, rows, n_w), h, 'kid_pack_emigrants_pair')
+    write(*,'(a,i0,a,i0,a,i0)') 'migration: width ', bw, ' east ', n_e, ' west ', n_w
+    if (n_e > 0) write(*,'(a,i0,a,i0)') 'migration: first east record ine ', nint(obuf_e(24,1)), ' id_ij ', nint(obuf_e(33,1), c_int64_t)
+  end block
   call kid_check(kid_destroy(h), h, 'kid_destroy')
 
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace', action='write')

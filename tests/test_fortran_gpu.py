@@ -120,6 +120,11 @@ def test_fortran_coupling_front_end(oracle, tmp_path, staggers):
     p = S.default_params()
     p.current_year, p.current_yearday = 3, 41.5
     b = S.place_bergs(grid, 300, 5, (3, 57), (3, 197))
+    d0, st0 = grid["desc"], grid["static"]
+    for k in range(3):       # three bergs start in the first halo column east of the domain: the first step deletes them as leavers (FW:3028)
+        b["ine"][k] = d0.iec + 1
+        b["lon"][k] = b["lon_old"][k] = st0["lon"][b["jne"][k] - d0.jsd, d0.iec - d0.isd] + 3.0
+        b["xi"][k] = 0.5
     cp = S.calving_params(p)
     ncalls, cap = 4, 12000
     st_code = {"B": T.ENUMS["KID_BGRID_NE"], "C": T.ENUMS["KID_CGRID_NE"], "A": T.ENUMS["KID_AGRID"]}
@@ -196,6 +201,17 @@ def test_fortran_coupling_front_end(oracle, tmp_path, staggers):
     for name in ("lon", "lat", "uvel", "vvel", "mass", "thickness", "heat_density", "start_day"):
         rv, gv = bergs[name][:bergs["_n"]][ra][ro], gb[name][ga][go]
         assert np.allclose(gv, rv, rtol=1e-10, atol=1e-12), (name, float(np.abs(gv - rv).max()))
+    # the migration entry points through the Fortran module: the driver packed east + west after the download
+    import re
+    m = re.search(r"migration: width (\d+) east (\d+) west (\d+)", r.stdout)
+    assert m, r.stdout
+    out_e = (gb["ine"] > d.iec) & (gb["halo_berg"] < 0.5)
+    out_w = (gb["ine"] < d.isc) & (gb["halo_berg"] < 0.5)
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (34, int(out_e.sum()), int(out_w.sum())), (m.groups(), int(out_e.sum()), int(out_w.sum()))
+    assert int(m.group(2)) >= 3                              # the three planted leavers at least
+    m2 = re.search(r"first east record ine (\d+) id_ij (-?\d+)", r.stdout)
+    if out_e.any():
+        assert m2 and int(m2.group(1)) == d.iec + 1 and int(m2.group(2)) in set((gb["id"][out_e] & 0xffffffff).astype(np.int64).tolist() + ((gb["id"][out_e] & 0xffffffff) - (1 << 32)).tolist())
     # the files the Fortran driver wrote from the resident state (write_restart_bergs, write_trajectory), read independently
     from scipy.io import netcdf_file
     with netcdf_file(str(rdir / "icebergs.res.nc"), "r", mmap=False) as f:

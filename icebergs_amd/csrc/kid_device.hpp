@@ -13,6 +13,11 @@
 
 namespace kid {
 
+// Measurement-only macros (KID_EXP_*) change what the library computes or how it is laid out; they are honoured only
+// together with -DKID_EXPERIMENTS, which kid_version() reports, so that a stray -D cannot ship wrong answers silently.
+#if !defined(KID_EXPERIMENTS) && (defined(KID_EXP_MARKERS) || defined(KID_EXP_NO_ATOMICS) || defined(KID_EXP_MAXRUN) || defined(KID_EXP_CHUNK) || defined(KID_EXP_NUM_VGPR))
+#error "KID_EXP_* macros are measurement-only: build with -DKID_EXPERIMENTS to use them"
+#endif
 // Keeps the machine scheduler from interleaving two long phases (each wants ~100 VGPRs for its own loads in
 // flight); without it the RK4 stage body needs ~300 registers and spills, with it the kernel fits 2-3 waves/SIMD.
 #ifdef KID_EXP_MARKERS
@@ -21,6 +26,54 @@ namespace kid {
 #define KID_MARK(name) ((void)0)
 #endif
 #define KID_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// ---------------------------------------------------------------------------------------------------------
+// Namelist switches as the device code sees them.  K = 0: read from kid_params at run time (any namelist).
+// K = 1: the "plain" namelist -- every switch below at the value icebergs_nml gives it by default (FW:686-822; BASELINE
+// configs 1-2: drag + Coriolis + melt, no bonds, no footloose, no diagnostics planes) -- folded at compile time, so that
+// the hot build of that namelist carries none of the other branches (code size, scalar registers).  The host picks
+// K = 1 only when every one of these switches has exactly this value (plain_namelist() in kid_hip.hip).
+// ---------------------------------------------------------------------------------------------------------
+#define KID_SWITCHES(X)                                                                                              \
+  X(old_bug_bilin, 1) X(coastal_drift, 0.) X(cdrag_grounding, 0.) X(use_new_predictive_corrective, 0)                 \
+  X(iceberg_bonds_on, 0) X(internal_bergs_for_drag, 0) X(hexagonal_icebergs, 0) X(speed_limit, 0.)                    \
+  X(override_iceberg_velocities, 0) X(use_f_plane, 0) X(use_updated_rolling_scheme, 0) X(tip_parameter, 0.)           \
+  X(use_mixed_melting, 0) X(melt_icebergs_as_ice_shelf, 0) X(set_melt_rates_to_zero, 0) X(use_operator_splitting, 1)  \
+  X(footloose, 0) X(bergy_bit_erosion_fraction, 0.) X(diag_mask, 0) X(allow_bergs_to_roll, 1)                         \
+  X(Iceberg_melt_without_decay, 0) X(grounding_fraction, 0.) X(clipping_depth, 0.) X(use_old_spreading, 1)            \
+  X(add_weight_to_ocean, 1) X(time_average_weight, 0) X(find_melt_using_spread_mass, 0) X(mts, 0) X(dem, 0)
+template <int K> struct Sw {
+#define KID_X(name, plain) static __device__ __forceinline__ auto name(const kid_params &p) -> decltype(p.name) { if constexpr (K == 1) return (decltype(p.name))(plain); else return p.name; }
+  KID_SWITCHES(KID_X)
+#undef KID_X
+};
+
+// Division and square root.  The IEEE expansions cost ~12 (division) and ~16 (square root) instructions each, a fifth of
+// the hot build.  Unless -DKID_EXACT_MATH, a quotient is a product with a Newton-refined v_rcp_f64 (error <= ~1.5 ulp
+// instead of 0.5), so that divisors which repeat (M, the cell area, dt, W+L, ...) are inverted once; results then differ
+// from the oracle's at the 1e-16 level (tolerance 1e-10), like the other trims.
+#ifdef KID_EXACT_MATH
+struct Rcp { double d; };
+__device__ __forceinline__ Rcp kid_rcp(double b) { return Rcp{b}; }
+__device__ __forceinline__ double operator*(double a, Rcp r) { return a / r.d; }
+__device__ __forceinline__ double kid_div(double a, double b) { return a / b; }
+#else
+struct Rcp { double r; };
+__device__ __forceinline__ Rcp kid_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);          // ~2^-26 relative
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);                  // <= 1 ulp
+  return Rcp{r};
+}
+__device__ __forceinline__ double operator*(double a, Rcp r) { return a * r.r; }
+__device__ __forceinline__ double kid_div(double a, double b) {  // one more correction: <= ~0.6 ulp
+  const Rcp r = kid_rcp(b);
+  const double q = a * r.r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r.r, q);
+}
+#endif
 
 // reference module constants, IB:68-80
 constexpr double RHO_ICE = 916.7, RHO_AIR = 1.1, RHO_SEAWATER = 1025.0, GRAVITY = 9.8;
@@ -41,6 +94,10 @@ struct DevGrid {
   const TrcRec *trc;
   const GeoRec *geo;
   const double *dx, *dy, *ocean_depth, *ssh;
+  // 1.0 where the hot build may step a berg of this cell: all four corner cells inside the data domain, no corner at the
+  // pole, and the corners a strictly convex quadrilateral -- then "(xi, yj) inside the unit square" and the reference's
+  // point-in-cell test (FW:6076-6160) are the same statement and the hot build tests the former (pack_static_kernel)
+  const double *hotok;
   // Parameter-only subexpressions of the hot loop, evaluated once on the host with the same IEEE operations (so the
   // results are the ones every lane used to compute for itself, per RK4 stage): sin(pi/180*lat_ref) alone was 7 % of
   // the step
@@ -49,6 +106,9 @@ struct DevGrid {
   double fl_e1;  // exp(pi/4) of the footloose foot length (IB:2538)
   __device__ __forceinline__ int idx(int i, int j) const { return (i - isd) + (j - jsd) * ni; }
 };
+
+// the plain build (K = 1) is for lat-lon grids (grid_is_latlon is the namelist default)
+template <int K> __device__ __forceinline__ bool grid_latlon(const DevGrid &g) { if constexpr (K == 1) return true; else return g.latlon != 0; }
 
 struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; };
 
@@ -64,7 +124,7 @@ struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; 
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) int lds_int;
-enum { PK_VEL = 0, PK_CORNER = 32, PK_T0 = 40, PK_DDX = 45, PK_DDY = 51, PK_AREA = 57, PK_MSK = 58, PK_SIZE = 67, PK_STRIDE = 68 };
+enum { PK_VEL = 0, PK_CORNER = 32, PK_T0 = 40, PK_DDX = 45, PK_DDY = 51, PK_AREA = 57, PK_MSK = 58, PK_HOTOK = 67, PK_SIZE = 68, PK_STRIDE = 68 };
 struct Corners { double lon00, lat00, lon10, lat10, lon11, lat11, lon01, lat01; };
 
 struct GlbCell {
@@ -95,6 +155,7 @@ struct PkCell {
   __device__ __forceinline__ double ddy(int k) const { return pk[PK_DDY + k]; }
   __device__ __forceinline__ double area() const { return pk[PK_AREA]; }
   __device__ __forceinline__ double msk(int di, int dj) const { return pk[PK_MSK + (di + 1) + 3 * (dj + 1)]; }
+  __device__ __forceinline__ bool hotok() const { return pk[PK_HOTOK] != 0.; }
 };
 template <bool FAST> struct CellOf;
 template <> struct CellOf<true> {
@@ -129,15 +190,19 @@ __device__ __forceinline__ PacketSrc packet_source(const DevGrid &g, int q) {
     arr = reinterpret_cast<const char *>(g.trc); stride = sizeof(TrcRec); field = 6; cell_off = (1 - (k % 3)) - (k / 3) * g.ni;
   } else if (q == PK_AREA) {
     arr = reinterpret_cast<const char *>(g.geo); stride = sizeof(GeoRec); field = 2; cell_off = 0;
-  } else {
-    const int m = (q < PK_SIZE) ? q - PK_MSK : 4;
+  } else if (q < PK_HOTOK) {
+    const int m = q - PK_MSK;
     arr = reinterpret_cast<const char *>(g.geo); stride = sizeof(GeoRec); field = 3; cell_off = (m % 3 - 1) + (m / 3 - 1) * g.ni;
+  } else {
+    arr = reinterpret_cast<const char *>(g.hotok); stride = sizeof(double); field = 0; cell_off = 0;
   }
   return PacketSrc{arr + cell_off * stride + field * 8, stride};
 }
 
-__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
-__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+// v_min_f64 / v_max_f64 (one instruction each; `a < b ? a : b` is a compare and two selects).  Same result unless an
+// operand is a NaN, which the path never feeds them.
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double sign1(double b) { return copysign(1.0, b); }
 
 // Fortran MODULO(a,p), p>0 (FW:6568).  A longitude handed to it lies inside the window [0,p) in all but the
@@ -234,16 +299,17 @@ __device__ __forceinline__ bool calc_xiyj(double x1, double x2, double x3, doubl
     const double d = 0.25 * (b * b) - a * c;
     if (d >= 0.) {
       const double sd = sqrt(d);
-      const double yy1 = -(0.5 * b + sd) / a, yy2 = -(0.5 * b - sd) / a;
+      const Rcp ra = kid_rcp(a);
+      const double yy1 = -(0.5 * b + sd) * ra, yy2 = -(0.5 * b - sd) * ra;
       yj = (fabs(yy1 - 0.5) < fabs(yy2 - 0.5)) ? yy1 : yy2;
     } else { ok = false; yj = -999.; }
   } else {
-    yj = (b != 0.) ? -c / b : 0.;
+    yj = (b != 0.) ? kid_div(-c, b) : 0.;
   }
   a = (alpha + gamma * yj);
   b = (delta + kappa * yj);
-  if (a != 0.) xi = (dx - beta * yj) / a;
-  else if (b != 0.) xi = (dy - epsilon * yj) / b;
+  if (a != 0.) xi = kid_div(dx - beta * yj, a);
+  else if (b != 0.) xi = kid_div(dy - epsilon * yj, b);
   else {
     c = (epsilon * alpha - beta * delta) + (epsilon * gamma - beta * kappa) * yj;
     if (c != 0.) xi = (epsilon * dx - beta * dy) / c; else { ok = false; xi = -999.; }
@@ -274,9 +340,24 @@ __device__ __noinline__ void pos_within_polar_cell(const DevGrid &g, const kid_p
 // FAST: the specialised hot-path build.  Anything rare (polar cells, a berg leaving its cell, the polar tangent
 // plane) sets `bail` instead of being handled; the kernel then leaves that berg untouched and queues it for the
 // general (FAST=false) build of the same code, which runs on the short list of such bergs.
-template <bool FAST, class CELL>
+// A berg of the hot build sits in a cell with hotok = 1 (checked once per step), so "in the cell" is "(xi, yj) in the unit
+// square"; within HOT_EDGE of an edge, where rounding could make the two tests differ, the berg goes to the general build.
+constexpr double HOT_EDGE = 1.e-8;
+template <bool FAST, int K = 0, class CELL>
 __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_params &p, const CELL &cell, double x, double y, int i, int j,
                                                 double &xi, double &yj, int &err, bool &bail) {
+  if constexpr (FAST) {
+    const Corners q = cell.corners();
+    if (!grid_latlon<K>(g) && g.regular) {
+      const double ddx = fabs(q.lon11 - q.lon01), ddy = fabs(q.lat11 - q.lat10);
+      const double x1 = q.lon11 - (ddx / 2), y1 = q.lat11 - (ddy / 2);
+      xi = kid_div(mod_around(x, x1, g.Lx) - x1, ddx) + 0.5;
+      yj = kid_div(y - y1, ddy) + 0.5;
+    } else if (!calc_xiyj(q.lon00, q.lon10, q.lon11, q.lon01, q.lat00, q.lat10, q.lat11, q.lat01, x, y, xi, yj, g.Lx)) err = 1;
+    const bool inside = (dmin(xi, yj) > HOT_EDGE) && (dmax(xi, yj) < 1. - HOT_EDGE);
+    if (!inside) bail = true;
+    return inside;
+  }
   xi = -999.; yj = -999.;
   if (!cell_in_data_domain(g, i, j)) return false;
   const Corners q = cell.corners();
@@ -284,8 +365,8 @@ __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_para
     const double ddx = fabs(q.lon11 - q.lon01), ddy = fabs(q.lat11 - q.lat10);
     const double x1 = q.lon11 - (ddx / 2), y1 = q.lat11 - (ddy / 2);
     const double Delta_x = mod_around(x, x1, g.Lx) - x1;
-    xi = ((Delta_x) / ddx) + 0.5;
-    yj = ((y - y1) / ddy) + 0.5;
+    xi = kid_div(Delta_x, ddx) + 0.5;
+    yj = kid_div(y - y1, ddy) + 0.5;
   } else if (!g.latlon || dmax(dmax(dmax(q.lat00, q.lat10), q.lat11), q.lat01) < 89.999) {
     if (!calc_xiyj(q.lon00, q.lon10, q.lon11, q.lon01, q.lat00, q.lat10, q.lat11, q.lat01, x, y, xi, yj, g.Lx)) err = 1;
   } else {  // polar cell: co-latitude tangent plane (FW:6359-6404), cold and out of line
@@ -311,21 +392,22 @@ __device__ __forceinline__ void bilin_lonlat(const DevGrid &g, const kid_params 
 // ---------------------------------------------------------------------------------------------------------
 // IB:4718-4900 interp_flds (non-MTS; tidal_drift = 0)
 // ---------------------------------------------------------------------------------------------------------
-template <class CELL>
+template <int K = 0, class CELL>
 __device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cell, double xi, double yj, Env &e) {
   double wx1, wx0, wy1, wy0;  // weights of columns i / i-1 and rows j / j-1 (FW:7081-7087)
-  if (p.old_bug_bilin) { wx1 = 1. - xi; wx0 = xi; wy1 = 1. - yj; wy0 = yj; }
+  if (Sw<K>::old_bug_bilin(p)) { wx1 = 1. - xi; wx0 = xi; wy1 = 1. - yj; wy0 = yj; }
   else { wx1 = xi; wx0 = 1. - xi; wy1 = yj; wy0 = 1. - yj; }
 #define KID_BIL(f) ((cell.vel(3, f) * wx1 + cell.vel(2, f) * wx0) * wy1 + (cell.vel(1, f) * wx1 + cell.vel(0, f) * wx0) * wy0)
   const double cos_rot = KID_BIL(0), sin_rot = KID_BIL(1);
   double uo = KID_BIL(2), vo = KID_BIL(3), ui = KID_BIL(4), vi = KID_BIL(5), ua = KID_BIL(6), va = KID_BIL(7);
 #undef KID_BIL
-  if (p.coastal_drift > 0.) {  // IB:4769-4776
+  if (Sw<K>::coastal_drift(p) > 0.) {  // IB:4769-4776
+    const double cd = Sw<K>::coastal_drift(p);
     const double mE = cell.msk(1, 0), mW = cell.msk(-1, 0), mN = cell.msk(0, 1), mS = cell.msk(0, -1), m0 = cell.msk(0, 0);
-    uo = uo + p.coastal_drift * (mE - mW) * m0;
-    ui = ui + p.coastal_drift * (mE - mW) * m0;
-    vo = vo + p.coastal_drift * (mN - mS) * m0;
-    vi = vi + p.coastal_drift * (mN - mS) * m0;
+    uo = uo + cd * (mE - mW) * m0;
+    ui = ui + cd * (mE - mW) * m0;
+    vo = vo + cd * (mN - mS) * m0;
+    vi = vi + cd * (mN - mS) * m0;
   }
   // sea-surface slope from the hoisted per-cell stencils (IB:4830-4860)
   double hxp, hxm;
@@ -362,45 +444,61 @@ __device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cel
 // ---------------------------------------------------------------------------------------------------------
 struct BergGeom { double M, T, W, L; int n_bonds; };
 
-template <bool RK>
-__device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &e,
+// What accel computes from the berg's size and from the tracer-point values of its cell (hi, od) alone: the drag
+// coefficients, the grounding drag, the size factors of the wave-radiation force (IB:2050-2130).  A berg of the hot
+// build stays in its cell, so these are the same in all four RK4 stages and are evaluated once per step (the general
+// build, whose berg may change cells between stages, evaluates them per stage) -- the same expressions either way.
+struct AccelPre { double c_gnd, c_ocn, c_atm, c_ice, pref_wave, F, WL2, L; Rcp rWpL; };
+template <int K = 0>
+__device__ __forceinline__ AccelPre accel_pre(const DevGrid &g, const kid_params &p, const BergGeom &bg, double hi_cell, double od) {
+  AccelPre a;
+  const double M = bg.M, T = bg.T, W = bg.W, L = bg.L;
+  const Rcp rM = kid_rcp(M);
+  const double D = g.rho_ratio * T, F = T - D;
+  const double hi = dmin(hi_cell, D), D_hi = dmax(0., D - hi);
+  a.c_gnd = 0.;
+  if (Sw<K>::cdrag_grounding(p) != 0.) {  // grounding drag IB:2068-2082 (cdrag_grounding = 0: c_gnd = 0 whatever groundfrac is)
+    double groundfrac;
+    if (p.h_to_init_grounding > 0.0) {
+      groundfrac = 1.0 - kid_div(od - D, p.h_to_init_grounding);
+      groundfrac = dmax(groundfrac, 0.0); groundfrac = dmin(groundfrac, 1.0);
+    } else groundfrac = (D > od) ? 1.0 : 0.0;
+    if (groundfrac > 0.0) a.c_gnd = (Sw<K>::cdrag_grounding(p) * W * L * groundfrac) * rM;
+  }
+  double dragfrac = 1.0;
+  if (Sw<K>::iceberg_bonds_on(p) && Sw<K>::internal_bergs_for_drag(p)) {
+    const double N_max = Sw<K>::hexagonal_icebergs(p) ? 6.0 : 4.0;
+    dragfrac = ((N_max - (double)bg.n_bonds) / N_max);
+  }
+  a.c_ocn = RHO_SEAWATER * rM * p.ocean_drag_scale * (0.5 * CD_WV * dragfrac * W * (D_hi) + CD_WH * W * L);
+  a.c_atm = RHO_AIR * rM * (0.5 * CD_AV * dragfrac * W * F + CD_AH * W * L);
+  a.c_ice = (fabs(hi) == 0.) ? 0. : RHO_ICE * rM * (0.5 * CD_IV * dragfrac * W * hi);
+  a.pref_wave = (0.5 * RHO_SEAWATER) * rM;
+  a.F = F; a.WL2 = 2. * W * L; a.L = L; a.rWpL = kid_rcp(W + L);
+  return a;
+}
+
+template <bool RK, int K = 0>
+__device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, const AccelPre &ap, const Env &e,
                                       int i, int j, double sin_lat, double uvel, double vvel, double uvel0, double vvel0,
                                       double dt, double &ax, double &ay, double &axn, double &ayn, double &bxn, double &byn,
                                       unsigned &tickets) {
   // RK: alpha=0, C_N=0, predictive-corrective per namelist; Verlet: alpha=C_N=1, predictive-corrective forced (IB:2002-2013)
-  const bool new_pc = RK ? (p.use_new_predictive_corrective != 0) : true;
+  const bool new_pc = RK ? (Sw<K>::use_new_predictive_corrective(p) != 0) : true;
   const double u_star = uvel0 + (axn * (dt / 2.)), v_star = vvel0 + (ayn * (dt / 2.));
   const double uo = e.uo, vo = e.vo, ui = e.ui, vi = e.vi, ua = e.ua, va = e.va;
   const double f_cori = (2. * p.omega) * sin_lat;  // IB:2043-2047, the caller picks lat or lat_ref
-  const double M = bg.M, T = bg.T, W = bg.W, L = bg.L;
-  const double D = g.rho_ratio * T, F = T - D;
-  const double hi = dmin(e.hi, D), D_hi = dmax(0., D - hi);
-  double c_gnd = 0.;
-  {  // grounding drag IB:2068-2082
-    double groundfrac;
-    if (p.h_to_init_grounding > 0.0) {
-      groundfrac = 1.0 - (e.od - D) / p.h_to_init_grounding;
-      groundfrac = dmax(groundfrac, 0.0); groundfrac = dmin(groundfrac, 1.0);
-    } else groundfrac = (D > e.od) ? 1.0 : 0.0;
-    if (groundfrac > 0.0) c_gnd = (p.cdrag_grounding * W * L * groundfrac) / M;
-  }
+  const double c_gnd = ap.c_gnd, c_ocn = ap.c_ocn, c_atm = ap.c_atm;
   // wave radiation IB:2085-2102
   double uwave = ua - uo, vwave = va - vo;
   double wmod = uwave * uwave + vwave * vwave;
   const double ampl = 0.5 * 0.02025 * wmod, Lwavelength = 0.32 * wmod;
   const double Lcutoff = 0.125 * Lwavelength, Ltop = 0.25 * Lwavelength;
-  const double Cr = 0.06 * dmin(dmax(0., (L - Lcutoff) / ((Ltop - Lcutoff) + 1.e-30)), 1.);
-  double wave_rad = 0.5 * RHO_SEAWATER / M * Cr * GRAVITY * ampl * dmin(ampl, F) * (2. * W * L) / (W + L);
+  const double Cr = 0.06 * dmin(dmax(0., kid_div(ap.L - Lcutoff, (Ltop - Lcutoff) + 1.e-30)), 1.);
+  double wave_rad = ap.pref_wave * Cr * GRAVITY * ampl * dmin(ampl, ap.F) * ap.WL2 * ap.rWpL;
   wmod = sqrt(ua * ua + va * va);
-  if (wmod != 0.) { uwave = ua / wmod; vwave = va / wmod; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
-  double dragfrac = 1.0;
-  if (p.iceberg_bonds_on && p.internal_bergs_for_drag) {
-    const double N_max = p.hexagonal_icebergs ? 6.0 : 4.0;
-    dragfrac = ((N_max - (double)bg.n_bonds) / N_max);
-  }
-  const double c_ocn = RHO_SEAWATER / M * p.ocean_drag_scale * (0.5 * CD_WV * dragfrac * W * (D_hi) + CD_WH * W * L);
-  const double c_atm = RHO_AIR / M * (0.5 * CD_AV * dragfrac * W * F + CD_AH * W * L);
-  double c_ice = (fabs(hi) == 0.) ? 0. : RHO_ICE / M * (0.5 * CD_IV * dragfrac * W * hi);
+  if (wmod != 0.) { const Rcp rw = kid_rcp(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
+  double c_ice = ap.c_ice;
   if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.;
   const double ex = -GRAVITY * e.ssh_x + wave_rad * uwave, ey = -GRAVITY * e.ssh_y + wave_rad * vwave;  // IB:2142-2149
   double axn_l, ayn_l, bxn_l, byn_l;
@@ -439,7 +537,7 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
     RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va) - drag_ice * (v_star - vi) - drag_gnd * v_star;
     const double lambda = drag_ocn + drag_atm + drag_ice + drag_gnd;
     const double A11 = 1. + 1.0 * dt * lambda, A22 = 1. + 1.0 * dt * lambda;
-    const double detA = 1. / ((A11 * A22) - (A12_0 * A21_0));
+    const double detA = 1. * kid_rcp((A11 * A22) - (A12_0 * A21_0));
     ax = detA * (A22 * RHS_x - A12_0 * RHS_y);
     ay = detA * (A11 * RHS_y - A21_0 * RHS_x);
     uveln = u_star + dt * ax;
@@ -448,16 +546,16 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   if (RK) { axn = 0.; ayn = 0.; }                                               // IB:2286
   else    { axn = ex + f_cori * vveln; ayn = ey - f_cori * uveln; }              // IB:2288-2297
   bxn = ax - (axn / 2); byn = ay - (ayn / 2);
-  if (p.speed_limit > 0. || p.speed_limit == -1.) {  // IB:2304-2323: only the ticket counter survives
+  if (Sw<K>::speed_limit(p) > 0. || Sw<K>::speed_limit(p) == -1.) {  // IB:2304-2323: only the ticket counter survives
     const double speed = sqrt(uveln * uveln + vveln * vveln);
     if (speed > 0.) {
       const int c = g.idx(i, j);
       const double loc_dx = dmin(0.5 * (g.dx[c] + g.dx[c - g.ni]), 0.5 * (g.dy[c] + g.dy[c - 1]));
-      const double new_speed = loc_dx / dt * p.speed_limit;
-      if (new_speed < speed && p.speed_limit > 0.) tickets += 1u;
+      const double new_speed = loc_dx / dt * Sw<K>::speed_limit(p);
+      if (new_speed < speed && Sw<K>::speed_limit(p) > 0.) tickets += 1u;
     }
   }
-  if (p.override_iceberg_velocities) { ax = 0.; ay = 0.; axn = 0.; ayn = 0.; bxn = 0.; byn = 0.; }
+  if (Sw<K>::override_iceberg_velocities(p)) { ax = 0.; ay = 0.; axn = 0.; ayn = 0.; bxn = 0.; byn = 0.; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -503,10 +601,10 @@ __device__ __forceinline__ void adjust_index_slow(const DevGrid &g, const kid_pa
   bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
   (void)pos_within_cell<false>(g, p, GlbCell{g, g.idx(i, j)}, lon, lat, i, j, xi, yj, err, unused_bail);
 }
-template <bool FAST>
+template <bool FAST, int K = 0>
 __device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, const lds_double *pk, double &lon, double &lat,
                                                         int &i, int &j, double &xi, double &yj, int &err, bool &bail) {
-  if (pos_within_cell<FAST>(g, p, CellOf<FAST>::make(g, pk, i, j), lon, lat, i, j, xi, yj, err, bail)) return;  // the common case: still in its cell
+  if (pos_within_cell<FAST, K>(g, p, CellOf<FAST>::make(g, pk, i, j), lon, lat, i, j, xi, yj, err, bail)) return;  // the common case: still in its cell
   if (FAST) bail = true;
   else adjust_index_slow(g, p, lon, lat, i, j, xi, yj, err);
 }
@@ -538,13 +636,14 @@ __device__ __noinline__ void rotvec_from_tang(const kid_params &p, double lon, d
 
 // sin(lat) for Coriolis (IB:2043-2047) and the metric dlon/dx (IB:462-477) share one argument reduction
 struct LatTerms { double sin_f, dxdl, s, c; };
+template <int K = 0>
 __device__ __forceinline__ LatTerms lat_terms(const DevGrid &g, const kid_params &p, double lat, double sin_ref) {
   LatTerms t;
-  if (g.latlon) {
+  if (grid_latlon<K>(g)) {
     double s, c;
     sincos(lat * g.pi_180, &s, &c);
-    t.dxdl = g.r180_pi / (p.Rearth * c);
-    t.sin_f = p.use_f_plane ? sin_ref : s;
+    t.dxdl = g.r180_pi * kid_rcp(p.Rearth * c);
+    t.sin_f = Sw<K>::use_f_plane(p) ? sin_ref : s;
     t.s = s; t.c = c;
   } else { t.dxdl = 1.; t.sin_f = sin_ref; t.s = 0.; t.c = 1.; }
   return t;
@@ -553,14 +652,15 @@ __device__ __forceinline__ LatTerms lat_terms(const DevGrid &g, const kid_params
 // RK4 stages 2-4 sit within a few hundred metres of stage 1: sin/cos of lat1 + d come from the angle-addition formulas
 // with a 5th/4th-order Taylor series in d (|d| < 2e-3 rad: truncation < 1e-17), ~20 instructions instead of a sincos
 // with argument reduction (~150).  Not bitwise equal to sincos(lat) (differences ~1e-16); -DKID_EXACT_MATH keeps sincos.
+template <int K = 0>
 __device__ __forceinline__ LatTerms lat_terms_near(const DevGrid &g, const kid_params &p, double lat, double sin_ref,
                                                    double lat1, double s1, double c1) {
 #ifdef KID_EXACT_MATH
   (void)lat1; (void)s1; (void)c1;
-  return lat_terms(g, p, lat, sin_ref);
+  return lat_terms<K>(g, p, lat, sin_ref);
 #else
   LatTerms t;
-  if (!g.latlon) { t.dxdl = 1.; t.sin_f = sin_ref; t.s = 0.; t.c = 1.; return t; }
+  if (!grid_latlon<K>(g)) { t.dxdl = 1.; t.sin_f = sin_ref; t.s = 0.; t.c = 1.; return t; }
   const double d = (lat - lat1) * g.pi_180;
   double s, c;
   if (fabs(d) < 2.e-3) {
@@ -569,8 +669,8 @@ __device__ __forceinline__ LatTerms lat_terms_near(const DevGrid &g, const kid_p
     const double cd = 1. - d2 * 0.5 * (1. - d2 * (1. / 12.));
     s = s1 * cd + c1 * sd; c = c1 * cd - s1 * sd;
   } else sincos(lat * g.pi_180, &s, &c);
-  t.dxdl = g.r180_pi / (p.Rearth * c);
-  t.sin_f = p.use_f_plane ? sin_ref : s;
+  t.dxdl = g.r180_pi * kid_rcp(p.Rearth * c);
+  t.sin_f = Sw<K>::use_f_plane(p) ? sin_ref : s;
   t.s = s; t.c = c;
   return t;
 #endif
@@ -603,17 +703,27 @@ struct BergDyn {
 // B=(x2[+x3]) per quantity.  On the polar tangent plane (lat>89, IB:7393) the same loop advances the
 // tangent-plane position/velocity instead; its rot* helpers are out of line (cold).
 // ---------------------------------------------------------------------------------------------------------
-template <bool OLD_ORDER, bool FAST>
+template <bool OLD_ORDER, bool FAST, int K = 0>
 __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
                                          BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
   const double dt = p.dt, dt_2 = 0.5 * dt, dt_6 = dt / 6.;
   const double sin_ref = g.sin_lat_ref;
-  const double dydl = g.latlon ? g.dydl : 1.;
+  const double dydl = grid_latlon<K>(g) ? g.dydl : 1.;
   const int i1 = d.ine, j1 = d.jne;
   const double xi1 = d.xi, yj1 = d.yj, lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
   const bool on_tang = FAST ? false : ((lat1 > 89.) && g.latlon);
-  if (FAST && (lat1 > 89.) && g.latlon) { bail = true; return; }
+  if (FAST && (lat1 > 89.) && grid_latlon<K>(g)) { bail = true; return; }
   Env e = stored;
+  // the size- and cell-dependent factors of accel: once per step where the berg cannot change cells between stages (hot
+  // build) or carries its environment with it (.not.old_interp_flds_order), per stage otherwise
+  constexpr bool PRE_ONCE = FAST || !OLD_ORDER;
+  AccelPre ap;
+  if constexpr (FAST) {
+    const PkCell cell{pk};
+    if (!cell.hotok()) { bail = true; return; }
+    if (OLD_ORDER) ap = accel_pre<K>(g, p, bg, cell.t0(3), cell.t0(4));
+  }
+  if (!OLD_ORDER) ap = accel_pre<K>(g, p, bg, stored.hi, stored.od);
   double bxn = 0., byn = 0.;
   double x1 = 0., y1 = 0., xdot1 = 0., ydot1 = 0.;
   if (on_tang) { rotpos_to_tang(p, lon1, lat1, x1, y1); rotvec_to_tang(p, lon1, uvel1, vvel1, xdot1, ydot1); }
@@ -625,20 +735,21 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     KID_MARK("loop_top");
-    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
+    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST, K>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
     KID_PHASE_FENCE();
     KID_MARK("after_adjust");
     LatTerms lt;
-    if (s == 0) { lt = lat_terms(g, p, lat_s, sin_ref); s_lat1 = lt.s; c_lat1 = lt.c; }
-    else lt = lat_terms_near(g, p, lat_s, sin_ref, lat1, s_lat1, c_lat1);
+    if (s == 0) { lt = lat_terms<K>(g, p, lat_s, sin_ref); s_lat1 = lt.s; c_lat1 = lt.c; }
+    else lt = lat_terms_near<K>(g, p, lat_s, sin_ref, lat1, s_lat1, c_lat1);
     double qu = uvel_s * lt.dxdl, qv = vvel_s * dydl;          // u_k, v_k  IB:7412
     KID_PHASE_FENCE();
     double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
     KID_MARK("after_latterms");
-    if (OLD_ORDER) interp_flds(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e);
+    if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e);
+    if constexpr (!PRE_ONCE) ap = accel_pre<K>(g, p, bg, e.hi, e.od);
     KID_PHASE_FENCE();
     KID_MARK("after_interp");
-    accel<true>(g, p, bg, e, i, j, lt.sin_f, uvel_s, vvel_s, uvel1, vvel1, (s < 2) ? dt_2 : dt, ax, ay, axn_s, ayn_s, bxn, byn, tickets);
+    accel<true, K>(g, p, ap, e, i, j, lt.sin_f, uvel_s, vvel_s, uvel1, vvel1, (s < 2) ? dt_2 : dt, ax, ay, axn_s, ayn_s, bxn, byn, tickets);
     KID_PHASE_FENCE();
     KID_MARK("after_accel");
     double qax = ax, qay = ay, qaxn = axn_s, qayn = ayn_s;
@@ -686,8 +797,8 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   }
   i = i1; j = j1; xi = xi1; yj = yj1;
   KID_PHASE_FENCE();
-  adjust_index_and_ground<FAST>(g, p, pk, lonn, latn, i, j, xi, yj, err, bail);
-  if (p.override_iceberg_velocities) { uveln = p.u_override; vveln = p.v_override; }  // IB:7151-7154
+  adjust_index_and_ground<FAST, K>(g, p, pk, lonn, latn, i, j, xi, yj, err, bail);
+  if (Sw<K>::override_iceberg_velocities(p)) { uveln = p.u_override; vveln = p.v_override; }  // IB:7151-7154
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
   d.xi = xi; d.yj = yj; d.ine = i; d.jne = j;
 }
@@ -695,31 +806,32 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
 // ---------------------------------------------------------------------------------------------------------
 // IB:7203-7328 verlet_stepping + IB:7684-7764 update_verlet_position (non-interactive)
 // ---------------------------------------------------------------------------------------------------------
-template <bool OLD_ORDER, bool FAST>
+template <bool OLD_ORDER, bool FAST, int K = 0>
 __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
                                             BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
   const double dt = p.dt, dt_2 = 0.5 * dt;
   const double sin_ref = g.sin_lat_ref;
-  const double dydl = g.latlon ? g.dydl : 1.;
+  const double dydl = grid_latlon<K>(g) ? g.dydl : 1.;
   const double lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
   double axn = d.axn, ayn = d.ayn, bxn = d.bxn, byn = d.byn;
   d.uvel_prev = d.uvel - dt_2 * d.bxn; d.vvel_prev = d.vvel - dt_2 * d.byn;       // IB:7256
   const double uvel3 = uvel1 + (dt_2 * axn), vvel3 = vvel1 + (dt_2 * ayn);         // IB:7259-7260
-  const LatTerms lt = lat_terms(g, p, lat1, sin_ref);
+  if constexpr (FAST) { if (!PkCell{pk}.hotok() || ((lat1 > 89.) && g.latlon)) { bail = true; return; } }
+  const LatTerms lt = lat_terms<K>(g, p, lat1, sin_ref);
   Env e = stored;
-  if (OLD_ORDER) interp_flds(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e);
+  if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e);
+  const AccelPre ap = accel_pre<K>(g, p, bg, e.hi, e.od);
   KID_PHASE_FENCE();
   double ax1, ay1, uveln, vveln;
-  accel<false>(g, p, bg, e, d.ine, d.jne, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt, ax1, ay1, axn, ayn, bxn, byn, tickets);
+  accel<false, K>(g, p, ap, e, d.ine, d.jne, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt, ax1, ay1, axn, ayn, bxn, byn, tickets);
   const bool on_tang = FAST ? false : ((lat1 > 89.) && g.latlon);
-  if (FAST && (lat1 > 89.) && g.latlon) { bail = true; return; }
   if (on_tang) {
     double xdot3, ydot3, xddot1, yddot1;
     rotvec_to_tang(p, lon1, uvel3, vvel3, xdot3, ydot3);
     rotvec_to_tang(p, lon1, ax1, ay1, xddot1, yddot1);
     rotvec_from_tang(p, lon1, xdot3 + (dt * xddot1), ydot3 + (dt * yddot1), uveln, vveln);
   } else { uveln = uvel3 + (dt * ax1); vveln = vvel3 + (dt * ay1); }
-  if (p.override_iceberg_velocities) { uveln = p.u_override; vveln = p.v_override; }
+  if (Sw<K>::override_iceberg_velocities(p)) { uveln = p.u_override; vveln = p.v_override; }
   // update_verlet_position reads berg%uvel AFTER the write-back (IB:7161 then 7720): u_new + dt/2 (axn+bxn)
   const double uvel2 = uveln + (dt_2 * axn) + (dt_2 * bxn), vvel2 = vveln + (dt_2 * ayn) + (dt_2 * byn);
   double lonn, latn;
@@ -733,7 +845,7 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
     lonn = lon1 + (dt * u2); latn = lat1 + (dt * v2);
   }
   KID_PHASE_FENCE();
-  adjust_index_and_ground<FAST>(g, p, pk, lonn, latn, d.ine, d.jne, d.xi, d.yj, err, bail);
+  adjust_index_and_ground<FAST, K>(g, p, pk, lonn, latn, d.ine, d.jne, d.xi, d.yj, err, bail);
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
 }
 
@@ -741,19 +853,20 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
 // IB:3307-3364 rolling, IB:3370-3387 fl_bits_dimensions
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void swapd(double &x, double &y) { const double t = x; x = y; y = t; }
+template <int K = 0>
 __device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double &Wn, double &Ln) {
   const double q = p.rho_bergs / RHO_SEAWATER;
   const double Dn = q * Tn;
   if (Dn > 0.) {
-    if (!p.use_updated_rolling_scheme && p.tip_parameter < 999.) {          // scheme 3 (default)
+    if (!Sw<K>::use_updated_rolling_scheme(p) && Sw<K>::tip_parameter(p) < 999.) {          // scheme 3 (default)
       if (dmax(Wn, Ln) < sqrt(0.92 * (Dn * Dn) + 58.32 * Dn)) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
     } else {
       if (Wn > Ln) swapd(Ln, Wn);
-      if (!p.use_updated_rolling_scheme && p.tip_parameter >= 999.) {       // scheme 2
+      if (!Sw<K>::use_updated_rolling_scheme(p) && Sw<K>::tip_parameter(p) >= 999.) {       // scheme 2
         if (Wn < sqrt((6.0 * q * (1 - q) * (Tn * Tn)) - (12 * 6.0 * q * Tn))) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
       }
-      if (p.use_updated_rolling_scheme) {                                   // scheme 1
-        const double tip = (p.tip_parameter > 0.) ? p.tip_parameter : sqrt(6 * q * (1 - q));
+      if (Sw<K>::use_updated_rolling_scheme(p)) {                                   // scheme 1
+        const double tip = (Sw<K>::tip_parameter(p) > 0.) ? Sw<K>::tip_parameter(p) : sqrt(6 * q * (1 - q));
         if ((tip * Tn) > Wn) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
       }
     }

@@ -27,32 +27,42 @@
 #include "kid_device.hpp"
 #include "kid_thermo.hpp"
 #include "kid_footloose.hpp"
+#include "kid_berg_kernel.hpp"
 
 using namespace kid;
 
 namespace {
-
-enum : unsigned { PH_INTERP = 1u, PH_EVOLVE = 2u, PH_THERMO = 4u, PH_SPREAD = 8u, PH_FL = 16u, PH_TSPREAD = 32u };   // PH_FL: footloose_calving between evolve and thermodynamics
-
-struct BergPtrs {
-  double *f[KID_NB_F64];
-  int32_t *i[KID_NB_I32];
-  int64_t *id;
-  const double *orient;   // per-berg hexagon orientation from the bonds (IB:4004), or null: initial_orientation
-};
-struct Flags { int has_static, has_fl, store_env, footprint, no_diag; };   // no_diag: calculate_mass_on_ocean(with_diagnostics=.false.)  // footprint: area/Uvel/Vvel_on_ocean are read by somebody
 
 // -------------------------------------------------------------------------------------------------------
 // grid prepass kernels
 // -------------------------------------------------------------------------------------------------------
 struct GridPlanes { const double *st[KID_NGRID_STATIC]; const double *fo[KID_NFORCING]; };
 
-__global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec *geo, int ncell) {
+__global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec *geo, double *hotok, int ni, int nj, int latlon, double Lx) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncell) return;
+  if (c >= ni * nj) return;
   GeoRec r;
   r.lon = gp.st[KID_G_LON][c]; r.lat = gp.st[KID_G_LAT][c]; r.area = gp.st[KID_G_AREA][c]; r.msk = gp.st[KID_G_MSK][c];
   geo[c] = r;
+  // DevGrid::hotok: may the hot build step a berg of this cell?  Its in-cell test is "(xi, yj) inside the unit square",
+  // which is the reference's point-in-cell test (FW:6076-6160) exactly when the four corners form a strictly convex
+  // quadrilateral (the bilinear map of calc_xiyj is then one-to-one onto it); polar cells (FW:6359) and cells whose
+  // packet would reach outside the data domain are left to the general build.
+  const int il = c % ni, jl = c / ni;
+  double ok = 0.;
+  if (il >= 1 && jl >= 1 && il + 1 < ni && jl + 1 < nj) {
+    const double *lon = gp.st[KID_G_LON], *lat = gp.st[KID_G_LAT];
+    const double x0 = lon[c - ni - 1], y0 = lat[c - ni - 1];
+    const double x1 = mod_around(lon[c - ni], x0, Lx), y1 = lat[c - ni];
+    const double x2 = mod_around(lon[c], x0, Lx), y2 = lat[c];
+    const double x3 = mod_around(lon[c - 1], x0, Lx), y3 = lat[c - 1];
+    const double k0 = (x1 - x0) * (y2 - y1) - (y1 - y0) * (x2 - x1), k1 = (x2 - x1) * (y3 - y2) - (y2 - y1) * (x3 - x2);
+    const double k2 = (x3 - x2) * (y0 - y3) - (y3 - y2) * (x0 - x3), k3 = (x0 - x3) * (y1 - y0) - (y0 - y3) * (x1 - x0);
+    const bool convex = (k0 > 0. && k1 > 0. && k2 > 0. && k3 > 0.) || (k0 < 0. && k1 < 0. && k2 < 0. && k3 < 0.);
+    const bool polar = latlon && dmax(dmax(y0, y1), dmax(y2, y3)) >= 89.999;
+    if (convex && !polar) ok = 1.;
+  }
+  hotok[c] = ok;
 }
 
 // Optional extras fused into the per-cell prepass (kid_step_prepare): keep a copy of the ssh plane, zero the cell's
@@ -90,247 +100,6 @@ __global__ void __launch_bounds__(256) pack_forcing_kernel(GridPlanes gp, VelRec
     t.ddy = 2. * (ssh[c + ni] - ssh[c]) / (dy0 + dyp) * msk[c + ni] * msk[c];
   }
   trc[c] = t;
-}
-
-// -------------------------------------------------------------------------------------------------------
-// the per-berg kernel
-// -------------------------------------------------------------------------------------------------------
-#ifndef KID_WAVES_PER_EU
-#define KID_WAVES_PER_EU 2
-#endif
-// Two builds of the same body share the work of one phase:
-//   FAST=true  : every berg, specialised for the overwhelmingly common case (stays in its cell, not at the pole).
-//                A berg that meets anything else is left untouched and its index is appended to `redo`.
-//   FAST=false : the general code (cell hops, coast bounce, polar cells, tangent plane) over the `redo` list.
-// Keeping the rare branches out of the hot build roughly halves its register footprint (2 waves/SIMD, no scratch).
-#ifndef KID_GENERAL_WAVES_PER_EU
-#define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
-#endif
-struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;    // k0, klen: the rows the hot build covers in this launch
-              int *fl_cursor; int32_t *fl_counter; long long fl_capacity; int fl_iNg; };   // PH_FL: where footloose children go (FlChildCtx)
-// lane/step ("slow lane" schedule, launch_berg_lanes): lane[k] >= step means berg k is owned by general-build launches that
-// may still be running on the side stream; the hot build of this step leaves it alone.  A berg the hot build hands over
-// at step s gets lane = s + 1: the general build does its steps s and s + 1, the hot build has it back at s + 2.
-#ifdef KID_EXP_NUM_VGPR
-#define KID_NUM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(KID_EXP_NUM_VGPR)))
-#else
-#define KID_NUM_VGPR_ATTR
-#endif
-template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST>
-__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid *__restrict__ gtab, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
-                                                   double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
-  // The parameter block (142 dwords) and the 51 field pointers are read through device-memory tables on demand:
-  // as by-value kernel arguments they were all pinned in SGPRs, overflowed the scalar file and came back as
-  // thousands of v_readlane spill reloads per wave.
-  const kid_params &p = *pp;
-  const BergPtrs &b = *bt;
-  const DevGrid &g = *gtab;   // like the other two tables: read on demand, not pinned in ~50 SGPRs for the whole kernel
-  constexpr bool SCATTER = (PH & (PH_THERMO | PH_SPREAD)) != 0;
-  __shared__ double lds_vals[SCATTER ? KID_SEG_LDS_DOUBLES : 1];   // staging of the per-cell sums (kid_thermo.hpp)
-  __shared__ int lds_ints[KID_SEG_LDS_INTS];                         // run tables of the 4 waves
-  __shared__ double lds_pk[FAST ? 4 * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the 4 waves (hot build)
-  // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
-  const long long total = FAST ? redo.klen : (long long)(*redo.count);
-  const long long bdim = FAST ? 256ll : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
-  for (long long tid = (long long)blockIdx.x * bdim + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * bdim + threadIdx.x) : (tid - threadIdx.x < total));
-       tid += (long long)gridDim.x * bdim) {
-  const bool inrange = tid < total;
-  const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
-  const long long kk = inrange ? k : (n - 1);
-  bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
-  if (FAST && redo.lane) { if (was_alive && redo.lane[kk] >= redo.step) was_alive = false; }
-  if (__ballot(was_alive) == 0ull) continue;  // wave-uniform; every other lane stays to the end (wave-level sums below)
-  double *scal = acc + (size_t)KID_NACC * ncell;
-
-  BergDyn d;
-  d.ine = b.i[KID_BI_INE][kk]; d.jne = b.i[KID_BI_JNE][kk];
-  // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
-  Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);
-  const lds_double *pk = nullptr;
-  if (FAST) {
-    lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (KID_MAXRUN * PK_STRIDE);
-    const int lane = (int)__lane_id();
-    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const int myrun = __popcll(seg.heads & le) - 1;
-    // There are packets for KID_MAXRUN distinct cells per wave.  As the cell order decays between two re-binnings a
-    // wave collects out-of-place bergs, each a run of its own: the lanes of the runs beyond the KID_MAXRUN-th go to the
-    // general build one by one (handing over the whole wave made 15 % of the population take the slow path by the end
-    // of a 16-step interval).
-    if (myrun >= KID_MAXRUN) {
-      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
-      was_alive = false;
-    }
-    if (__ballot(was_alive) == 0ull) continue;
-    const int nstage = seg.R < KID_MAXRUN ? seg.R : KID_MAXRUN;
-    // lane q fetches packet elements q and q+64 of every distinct cell: where they live is fixed per lane
-    const PacketSrc s0 = packet_source(g, lane), s1 = packet_source(g, (lane < PK_SIZE - 64) ? 64 + lane : 0);
-    for (int r = 0; r < nstage; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
-      const int c = seg.cell[r];
-      if (c >= 0) {
-        wpk[r * PK_STRIDE + lane] = *reinterpret_cast<const double *>(s0.base + (long long)c * s0.stride);
-        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = *reinterpret_cast<const double *>(s1.base + (long long)c * s1.stride);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    pk = wpk + (myrun < KID_MAXRUN ? myrun : 0) * PK_STRIDE;
-  }
-  d.xi = b.f[KID_B_XI][kk]; d.yj = b.f[KID_B_YJ][kk];
-  d.lon = b.f[KID_B_LON][kk]; d.lat = b.f[KID_B_LAT][kk];
-  d.uvel = b.f[KID_B_UVEL][kk]; d.vvel = b.f[KID_B_VVEL][kk];
-  d.uvel_prev = 0.; d.vvel_prev = 0.;
-  BergThermo t;
-  t.alive = was_alive;
-  t.M = b.f[KID_B_MASS][kk]; t.T = b.f[KID_B_THICKNESS][kk]; t.W = b.f[KID_B_WIDTH][kk]; t.L = b.f[KID_B_LENGTH][kk];
-  t.n_bonds = p.iceberg_bonds_on ? b.i[KID_BI_N_BONDS][kk] : 0;
-  t.static_berg = fl.has_static ? b.f[KID_B_STATIC_BERG][kk] : 0.;
-  const bool halo = fl.has_static ? (b.f[KID_B_HALO_BERG][kk] >= 0.5) : false;
-  Env e = {};
-  unsigned tickets = 0u;
-  int err = 0;
-  bool env_dirty = false;
-  bool bail = false;     // FAST build: this berg needs the general build
-  bool skipped = false;  // ... and has been queued: nothing of it may be written or accumulated here
-
-  if ((PH & PH_INTERP) || (!OLD_ORDER && (PH & (PH_EVOLVE | PH_THERMO)))) {
-    if (PH & PH_INTERP) {  // IB:4673-4715
-      if (was_alive && !halo) { interp_flds(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e); env_dirty = true; }
-    } else {  // stored environment (.not.old_interp_flds_order), IB:2039-2040
-      e.uo = b.f[KID_B_UO][kk]; e.vo = b.f[KID_B_VO][kk]; e.ui = b.f[KID_B_UI][kk]; e.vi = b.f[KID_B_VI][kk];
-      e.ua = b.f[KID_B_UA][kk]; e.va = b.f[KID_B_VA][kk]; e.ssh_x = b.f[KID_B_SSH_X][kk]; e.ssh_y = b.f[KID_B_SSH_Y][kk];
-      e.sst = b.f[KID_B_SST][kk]; e.sss = b.f[KID_B_SSS][kk]; e.cn = b.f[KID_B_CN][kk]; e.hi = b.f[KID_B_HI][kk]; e.od = b.f[KID_B_OD][kk];
-    }
-  }
-
-  if (PH & PH_EVOLVE) {  // IB:7081-7179
-    d.axn = b.f[KID_B_AXN][kk]; d.ayn = b.f[KID_B_AYN][kk];
-    if (!RK) { d.bxn = b.f[KID_B_BXN][kk]; d.byn = b.f[KID_B_BYN][kk]; } else { d.bxn = 0.; d.byn = 0.; }
-    const bool moves = was_alive && (t.static_berg < 0.5);
-    if (moves) {
-      const BergGeom bg{t.M, t.T, t.W, t.L, t.n_bonds};
-      if (RK) rk4_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail, pk);
-      else verlet_step<OLD_ORDER, FAST>(g, p, bg, e, d, tickets, err, bail, pk);
-      if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
-        const int slot = atomicAdd(redo.count, 1);
-        redo.list[slot] = (int)kk;
-        if (redo.lane) redo.lane[kk] = redo.step + 1;
-        skipped = true; tickets = 0u; err = 0;
-      } else {
-        // a berg whose cell leaves the computational domain is packed-and-deleted by send_bergs_to_other_pes on a
-        // PE without that neighbour (FW:3024-3041)
-        if (d.ine < g.isc || d.ine > g.iec || d.jne < g.jsc || d.jne > g.jec) {
-          bool back = false;
-          if constexpr (!FAST) {  // (a berg of the hot build never changes its cell)
-            // periodic_reentry: the zonal seam treated as a boundary between two PEs: sent east/west (FW:3024-3041),
-            // unpacked on the other side with *_old reset (FW:3573-3577), the cell one period away accepted by the
-            // modulo-aware point-in-cell test (check_and_find_cell FW:3628), xi / yj recomputed (FW:3634), lon unchanged
-            const int nic = g.iec - g.isc + 1;
-            const int i2 = d.ine > g.iec ? d.ine - nic : (d.ine < g.isc ? d.ine + nic : d.ine);
-            if (p.periodic_reentry && g.Lx > 0. && d.jne >= g.jsc && d.jne <= g.jec && i2 >= g.isc && i2 <= g.iec) {
-              const GlbCell cell2{g, g.idx(i2, d.jne)};
-              int perr = 0; bool pbail = false;
-              double xi2, yj2;
-              if (!pos_within_cell<false>(g, p, cell2, d.lon, d.lat, i2, d.jne, xi2, yj2, perr, pbail)) err = 1;  // not in the cell one period away: 'can not find a cell to place berg in!' FW:3660
-              d.ine = i2; d.xi = xi2; d.yj = yj2;
-              b.f[KID_B_UVEL_OLD][kk] = d.uvel; b.f[KID_B_VVEL_OLD][kk] = d.vvel; b.f[KID_B_LON_OLD][kk] = d.lon; b.f[KID_B_LAT_OLD][kk] = d.lat;
-              back = true;
-            }
-          }
-          if (!back) t.alive = false;
-        }
-        b.f[KID_B_LON][kk] = d.lon; b.f[KID_B_LAT][kk] = d.lat; b.f[KID_B_UVEL][kk] = d.uvel; b.f[KID_B_VVEL][kk] = d.vvel;
-        b.f[KID_B_AXN][kk] = d.axn; b.f[KID_B_AYN][kk] = d.ayn; b.f[KID_B_BXN][kk] = d.bxn; b.f[KID_B_BYN][kk] = d.byn;
-        b.f[KID_B_XI][kk] = d.xi; b.f[KID_B_YJ][kk] = d.yj;
-        b.i[KID_BI_INE][kk] = d.ine; b.i[KID_BI_JNE][kk] = d.jne;
-        if (!RK) { b.f[KID_B_UVEL_PREV][kk] = d.uvel_prev; b.f[KID_B_VVEL_PREV][kk] = d.vvel_prev; }
-      }
-    }
-    const unsigned long long bt = __ballot(tickets != 0u);
-    if (bt) {  // rare
-      double ts = wave_sum((double)tickets);
-      if (__lane_id() == 0) unsafeAtomicAdd(scal + KID_S_NSPEEDING_TICKETS, ts);
-    }
-  }
-  KID_PHASE_FENCE();
-  KID_MARK("evolve_done");
-
-  if (PH & PH_FL) {  // footloose_calving (IB:5453, 2503-2734) on the berg's own rows between its evolve and its thermodynamics:
-    // per berg the reference's order is evolve -> footloose -> thermodynamics too, and nothing of another berg is read.
-    // The state goes through memory (this lane has just stored it); children are appended behind the population and get
-    // their thermodynamics + spreading from a second launch over the new rows (kid_step_local).
-    if (was_alive && !skipped && t.alive) {
-      const FlChildCtx cx{redo.fl_cursor, redo.fl_counter, n, redo.fl_capacity, redo.fl_iNg};
-      footloose_one(g, p, b, cx, kk, acc, ncell, scal);
-      t.M = b.f[KID_B_MASS][kk]; t.T = b.f[KID_B_THICKNESS][kk]; t.W = b.f[KID_B_WIDTH][kk]; t.L = b.f[KID_B_LENGTH][kk];
-    }
-  }
-
-  if (PH & (PH_THERMO | PH_SPREAD)) {
-    const bool active = t.alive && !skipped;
-    if (!FAST) seg = make_runs(active ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);  // cells may have changed
-    const typename CellOf<FAST>::type cellv = CellOf<FAST>::make(g, pk, d.ine, d.jne);
-    t.mass_scaling = b.f[KID_B_MASS_SCALING][kk];
-    t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk];
-    t.heat_density = (PH & PH_THERMO) ? b.f[KID_B_HEAT_DENSITY][kk] : 0.;
-    if (fl.has_fl) {
-      t.mass_of_fl_bits = b.f[KID_B_MASS_OF_FL_BITS][kk]; t.mass_of_fl_bergy_bits = b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk];
-      t.fl_k = b.f[KID_B_FL_K][kk];
-    } else { t.mass_of_fl_bits = 0.; t.mass_of_fl_bergy_bits = 0.; t.fl_k = 0.; }
-    t.start_mass = (p.diag_mask & KID_DIAG_MELT_BY_CLASS) ? b.f[KID_B_START_MASS][kk] : 0.;
-    t.start_year = 0; t.start_day = 0.;
-    if (PH & PH_THERMO) {
-      if (!OLD_ORDER && (PH & PH_EVOLVE) && (PH & PH_INTERP)) {  // fused step: interp_gridded_fields_to_bergs again at the new position, IB:5473
-        if (active) { interp_flds(p, cellv, d.xi, d.yj, e); env_dirty = true; }
-      }
-      if (OLD_ORDER || (!p.mts && !p.dem && halo)) {  // IB:2890-2894 (od is not passed there)
-        const double od_keep = e.od;
-        if (active) { interp_flds(p, cellv, d.xi, d.yj, e); env_dirty = true; }
-        if (PH & PH_INTERP) e.od = od_keep;
-      }
-      KID_PHASE_FENCE();
-      KID_MARK("thermo_interp_done");
-      const BergThermo before = t;
-      if constexpr ((PH & PH_TSPREAD) != 0) {  // thermodynamics spreads the would-be masses itself, IB:3219-3238
-        const TSpreadArgs ts{d.xi, d.yj, b.orient ? b.orient[kk] : p.initial_orientation, fl.footprint != 0};
-        thermodynamics<true>(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal, &ts);
-      } else thermodynamics(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
-      if (active) {
-        b.f[KID_B_MASS][kk] = t.M; b.f[KID_B_THICKNESS][kk] = t.T; b.f[KID_B_WIDTH][kk] = t.W; b.f[KID_B_LENGTH][kk] = t.L;
-        if (t.mass_of_bits != before.mass_of_bits) b.f[KID_B_MASS_OF_BITS][kk] = t.mass_of_bits;
-        if (fl.has_fl) {
-          b.f[KID_B_MASS_OF_FL_BITS][kk] = t.mass_of_fl_bits; b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk] = t.mass_of_fl_bergy_bits;
-          b.f[KID_B_FL_K][kk] = t.fl_k;
-          if (t.mass_scaling != before.mass_scaling) {  // converted to a footloose child (IB:3272-3289)
-            b.f[KID_B_MASS_SCALING][kk] = t.mass_scaling;
-            b.i[KID_BI_START_YEAR][kk] = t.start_year; b.f[KID_B_START_DAY][kk] = t.start_day;
-          }
-        }
-      }
-      KID_PHASE_FENCE();
-      KID_MARK("thermo_done");
-    }
-    if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
-      const bool act2 = t.alive && !skipped;
-      if ((p.add_weight_to_ocean && !p.time_average_weight) || p.find_melt_using_spread_mass)
-        spread_mass(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg, fl.footprint != 0,
-                    b.orient ? b.orient[kk] : p.initial_orientation);
-      if (!fl.no_diag) berg_diagnostics(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
-    }
-    seg_flush(seg, acc, ncell);
-    KID_MARK("spread_done");
-  }
-
-  if (was_alive && !skipped) {
-    if (!t.alive) b.i[KID_BI_ALIVE][kk] = 0;
-    if (env_dirty && fl.store_env) {
-      b.f[KID_B_UO][kk] = e.uo; b.f[KID_B_VO][kk] = e.vo; b.f[KID_B_UI][kk] = e.ui; b.f[KID_B_VI][kk] = e.vi;
-      b.f[KID_B_UA][kk] = e.ua; b.f[KID_B_VA][kk] = e.va; b.f[KID_B_SSH_X][kk] = e.ssh_x; b.f[KID_B_SSH_Y][kk] = e.ssh_y;
-      b.f[KID_B_SST][kk] = e.sst; b.f[KID_B_SSS][kk] = e.sss; b.f[KID_B_CN][kk] = e.cn; b.f[KID_B_HI][kk] = e.hi;
-      if (PH & PH_INTERP) b.f[KID_B_OD][kk] = e.od;
-    }
-  }
-  const unsigned long long be = __ballot(err != 0);
-  if (be && __lane_id() == 0) unsafeAtomicAdd(scal + KID_S_ERROR_COUNT, (double)__popcll(be));
-  }  // grid-stride loop
 }
 
 // footloose_calving (IB:2503-2734): streaming pass, one lane per berg that existed when the pass started
@@ -542,7 +311,7 @@ struct kid_handle {
   int64_t capacity = 0, n = 0;
   // device memory
   double *d_static[KID_NGRID_STATIC] = {}, *d_forcing[KID_NFORCING] = {};
-  VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr;
+  VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr; double *d_hotok = nullptr;
   double *d_acc_own = nullptr, *d_acc = nullptr;  // KID_NACC*ncell + KID_NSCALAR
   double *d_out = nullptr;                        // KID_NOUT*ncell
   double *d_totals = nullptr;                     // KID_NSCALAR running totals (the block's scalars are per-step)
@@ -618,7 +387,7 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.isd = h->gd.isd; g.ied = h->gd.ied; g.jsd = h->gd.jsd; g.jed = h->gd.jed;
   g.isc = h->gd.isc; g.iec = h->gd.iec; g.jsc = h->gd.jsc; g.jec = h->gd.jec;
   g.ni = h->ni; g.nj = h->nj; g.latlon = h->gd.grid_is_latlon; g.regular = h->gd.grid_is_regular; g.Lx = h->gd.Lx;
-  g.vel = h->forc_parity ? h->d_vel2 : h->d_vel; g.trc = h->forc_parity ? h->d_trc2 : h->d_trc; g.geo = h->d_geo;
+  g.vel = h->forc_parity ? h->d_vel2 : h->d_vel; g.trc = h->forc_parity ? h->d_trc2 : h->d_trc; g.geo = h->d_geo; g.hotok = h->d_hotok;
   g.dx = h->d_static[KID_G_DX]; g.dy = h->d_static[KID_G_DY]; g.ocean_depth = h->d_static[KID_G_OCEAN_DEPTH];
   g.ssh = h->d_forcing[KID_F_SSH];
   g.sin_lat_ref = sin((h->params.pi / 180.) * h->params.lat_ref);
@@ -713,6 +482,8 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_vel, h->ncell * sizeof(VelRec)));
   KID_HIP(h, hipMalloc(&h->d_trc, h->ncell * sizeof(TrcRec)));
   KID_HIP(h, hipMalloc(&h->d_geo, h->ncell * sizeof(GeoRec)));
+  KID_HIP(h, hipMalloc(&h->d_hotok, h->ncell * sizeof(double)));
+  KID_HIP(h, hipMemset(h->d_hotok, 0, h->ncell * sizeof(double)));
   const size_t accn = (size_t)KID_NACC * h->ncell + KID_NSCALAR;
   KID_HIP(h, hipMalloc(&h->d_acc_own, accn * sizeof(double)));
   KID_HIP(h, hipMemset(h->d_acc_own, 0, accn * sizeof(double)));
@@ -772,6 +543,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_vel) (void)hipFree(h->d_vel);
   if (h->d_trc) (void)hipFree(h->d_trc);
   if (h->d_geo) (void)hipFree(h->d_geo);
+  if (h->d_hotok) (void)hipFree(h->d_hotok);
   if (h->d_acc_own) (void)hipFree(h->d_acc_own);
   if (h->d_out) (void)hipFree(h->d_out);
   if (h->d_totals) (void)hipFree(h->d_totals);
@@ -912,7 +684,7 @@ static int pack_static(kid_handle *h) {
   for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
   for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = h->d_forcing[k];
   const int nb = (int)((h->ncell + 255) / 256);
-  hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, (int)h->ncell);
+  hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, h->d_hotok, h->ni, h->nj, (int)h->gd.grid_is_latlon, h->gd.Lx);
   KID_HIP(h, hipGetLastError());
   return KID_OK;
 }
@@ -1275,6 +1047,18 @@ int kid_zero_accumulators(kid_handle *h) {
 }  // extern "C"
 
 static int refresh_tables(kid_handle *h);
+// May the hot build be the plain one (berg_kernel<..., K = 1>, kid_device.hpp)?  Only when every switch of KID_SWITCHES
+// has the value that build folds in, and none of the handle's flags is set.
+static bool plain_namelist(const kid_handle *h) {
+  const kid_params &p = h->params;
+  bool same = true;
+#define KID_X(name, plain) same = same && (p.name == (decltype(p.name))(plain));
+  KID_SWITCHES(KID_X)
+#undef KID_X
+  const Flags &f = h->flags;
+  return same && h->gd.grid_is_latlon && !p.pass_fields_to_ocean_model && !f.has_static && !f.has_fl && !f.store_env && !f.footprint && !f.no_diag &&
+         getenv("KID_NO_PLAIN_BUILD") == nullptr;
+}
 template <unsigned PH>
 static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_len = -1) {   // range: the rows to step (default all)
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
@@ -1292,6 +1076,7 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
   // Pipelined (a side stream is set): two halves; the general build of a half runs on the side stream while the main
   // stream is already in the hot build of the other half (or of the next step): the ~85 us single-wave latency of the
   // general build leaves the critical path.  Events order a half's hot build behind its own previous general build.
+  const bool plain = plain_namelist(h);   // the hot build of the default namelist carries none of the other branches
   const int nparts = (h->pipelined && !h->params.mts && !h->params.footloose && h->n >= 4096 && range_len < 0) ? 2 : 1;
   const long long half = ((h->n / 2 + 255) / 256) * 256;
   for (int part = 0; part < nparts; ++part) {
@@ -1310,6 +1095,9 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
     }
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
+    if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                       \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(256), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    else                                                                                                                        \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \
     if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
@@ -1377,6 +1165,9 @@ static int launch_berg_lanes(kid_handle *h) {
     /* recorded even without a carry-over launch: everything enqueued on the side stream so far (the gather of the step  \
        before last included) is complete once the next prepass has waited for it */                                          \
     (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
+    if (RKV && OLDV && plain)                                                                                                   \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    else                                                                                                                        \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(evF, M);                                                                                               \
     if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }                                                    \
@@ -1392,6 +1183,7 @@ static int launch_berg_lanes(kid_handle *h) {
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(nbg), dim3(64), 0, S, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(h->evG[0], S); h->evG_live[0] = true;                                                                  \
   } while (0)
+  const bool plain = plain_namelist(h);
   const bool rebin_now = h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval && !h->have_bonds && getenv("KID_STABLE_RESORT") == nullptr;
   int rebin_rc = KID_OK;
   if (rk) KID_LAUNCH_LANES(true); else KID_LAUNCH_LANES(false);

@@ -145,25 +145,27 @@ __device__ __forceinline__ int minloc_abs10(const double *tab, double v) {  // F
 }
 
 // IB:2844-3300 thermodynamics for one berg.  Writes the new state into `b`, scatters into acc planes.
-template <class CELL>
+template <int K = 0, class CELL>
 __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
                                             int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg, bool footprint, double theta);
 // TSPREAD (find_melt_using_spread_mass with Iceberg_melt_without_decay, IB:3219-3238): the masses the berg WOULD have after
 // the step are spread onto the ocean from inside thermodynamics, before the berg is put back to what it was.  A compile-
 // time switch: the spreading code is inlined only into the launches of that namelist combination.
 struct TSpreadArgs { double xi, yj, theta; bool footprint; };
-template <bool TSPREAD = false, class CELL>
+template <bool TSPREAD = false, int K = 0, class CELL>
 __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_params &p, const CELL &cellv, BergThermo &b, const Env &e,
                                                double uvel, double vvel, double lat, int i, int j, bool active,
                                                double *acc, size_t ncell, Seg &seg, double *scal, const TSpreadArgs *ts = nullptr) {
   constexpr double perday = 1. / 86400.;
   const double dt = p.dt;
+  const Rcp rdt = kid_rcp(dt);   // the many x/dt below share one reciprocal (exact division with -DKID_EXACT_MATH)
   const int c = g.idx(i, j);
   const double SST = e.sst;
   double SSS = e.sss;
   const double IC = dmin(1., e.cn + p.sicn_shift);
   const double M = b.M, T = b.T, W = b.W, L = b.L;
   const double Vol = T * W * L;
+  const Rcp rVol = kid_rcp(Vol);
   double du = uvel - e.uo, dv = vvel - e.vo;
   const double dvo = sqrt(du * du + dv * dv);
   du = e.ua - e.uo; dv = e.va - e.vo;
@@ -175,48 +177,48 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
 #endif
   const double dvo08 = kid_powr(dvo, 0.8);
   double Mv = dmax(7.62e-3 * SST + 1.29e-3 * (SST * SST), 0.) * perday;
-  double Mb = dmax(0.58 * dvo08 * (SST + 4.0) / kid_powr(L, 0.2), 0.) * perday;
+  double Mb = dmax(0.58 * dvo08 * (SST + 4.0) * kid_rcp(kid_powr(L, 0.2)), 0.) * perday;
   double Me = dmax(1. / 12. * (SST + 2.) * Ss * (1 + cos(p.pi * (IC * IC * IC))), 0.) * perday;
   const bool has_fl = b.mass_of_fl_bits > 0.;
   const double Mv_fl = Mv, Me_fl = Me;  // IB:2924-2926
-  const double N_max = p.hexagonal_icebergs ? 6.0 : 4.0;
+  const double N_max = Sw<K>::hexagonal_icebergs(p) ? 6.0 : 4.0;
   double N_bonds = 0.;
-  if (p.use_mixed_melting || p.allow_bergs_to_roll) {
-    if (p.iceberg_bonds_on) N_bonds = (double)b.n_bonds;
+  if (Sw<K>::use_mixed_melting(p) || Sw<K>::allow_bergs_to_roll(p)) {
+    if (Sw<K>::iceberg_bonds_on(p)) N_bonds = (double)b.n_bonds;
     if (b.static_berg == 1) N_bonds = N_max;
   }
-  if (p.melt_icebergs_as_ice_shelf || p.use_mixed_melting) {  // IB:2947-2968
+  if (Sw<K>::melt_icebergs_as_ice_shelf(p) || Sw<K>::use_mixed_melting(p)) {  // IB:2947-2968
     if (!p.use_mixed_layer_salinity_for_thermo) SSS = 35.0;
     double Ms = dmax(find_basal_melt(g, p, dvo, lat, SSS, SST, p.Use_three_equation_model != 0, T), 0.);
     if ((p.melt_cutoff >= 0.) && p.apply_thickness_cutoff_to_bergs_melt) {
       const double Dn = (p.rho_bergs / RHO_SEAWATER) * T;
       if ((g.ocean_depth[c] - Dn) < p.melt_cutoff) Ms = 0.;
     }
-    if (p.use_mixed_melting) {
+    if (Sw<K>::use_mixed_melting(p)) {
       Me = ((N_max - N_bonds) / N_max) * (Mv + Me);
       Mv = 0.0;
       Mb = (((N_max - N_bonds) / N_max) * (Mb)) + (N_bonds / N_max) * Ms;
     } else { Mv = 0.0; Me = 0.0; Mb = Ms; }
   }
-  if (p.set_melt_rates_to_zero) { Mv = 0.0; Mb = 0.0; Me = 0.0; }
+  if (Sw<K>::set_melt_rates_to_zero(p)) { Mv = 0.0; Mb = 0.0; Me = 0.0; }
   double Tn, nVol, Mnew, dMb, dMv, dMe, dM, Ln1 = 0., Wn1 = 0., Ln, Wn;
-  if (p.use_operator_splitting) {  // IB:2976-2994
+  if (Sw<K>::use_operator_splitting(p)) {  // IB:2976-2994
     Tn = dmax(T - Mb * dt, 0.);
-    nVol = Tn * W * L; const double Mnew1 = (nVol / Vol) * M; dMb = M - Mnew1;
+    nVol = Tn * W * L; const double Mnew1 = (nVol * rVol) * M; dMb = M - Mnew1;
     Ln1 = dmax(L - Mv * dt, 0.); Wn1 = dmax(W - Mv * dt, 0.);
-    nVol = Tn * Wn1 * Ln1; const double Mnew2 = (nVol / Vol) * M; dMv = Mnew1 - Mnew2;
+    nVol = Tn * Wn1 * Ln1; const double Mnew2 = (nVol * rVol) * M; dMv = Mnew1 - Mnew2;
     Ln = dmax(Ln1 - Me * dt, 0.); Wn = dmax(Wn1 - Me * dt, 0.);
-    nVol = Tn * Wn * Ln; Mnew = (nVol / Vol) * M; dMe = Mnew2 - Mnew;
+    nVol = Tn * Wn * Ln; Mnew = (nVol * rVol) * M; dMe = Mnew2 - Mnew;
     dM = M - Mnew;
   } else {
     Ln = dmax(L - (Mv + Me) * (dt), 0.); Wn = dmax(W - (Mv + Me) * (dt), 0.); Tn = dmax(T - Mb * (dt), 0.);
-    nVol = Tn * Wn * Ln; Mnew = (nVol / Vol) * M; dM = M - Mnew;
-    dMb = (M / Vol) * (W * L) * Mb * dt;
-    dMe = (M / Vol) * (T * (W + L)) * Me * dt;
-    dMv = (M / Vol) * (T * (W + L)) * Mv * dt;
+    nVol = Tn * Wn * Ln; Mnew = (nVol * rVol) * M; dM = M - Mnew;
+    dMb = (M * rVol) * (W * L) * Mb * dt;
+    dMe = (M * rVol) * (T * (W + L)) * Me * dt;
+    dMv = (M * rVol) * (T * (W + L)) * Mv * dt;
   }
   double fl_k = b.fl_k;
-  if (p.footloose && fl_k >= 0) {  // IB:3011-3028
+  if (Sw<K>::footloose(p) && fl_k >= 0) {  // IB:3011-3028
     const double l_c = p.pi / (2. * sqrt(2.));
     const double l_b3 = 3. * l_c * kid_root4(FL_LW_C * p.fl_youngs * FL_B_C1 * kid_cube(Tn));
     if (L > l_b3) {
@@ -237,7 +239,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
     const double Mfl = b.mass_of_fl_bits, Volfl = Lfl * Wfl * Tfl;
     const double Mb_fl = dmax(0.58 * dvo08 * (SST + 4.0) / kid_powr(Lfl, 0.2), 0.) * perday;
     Tnfl = dmax(Tfl - Mb_fl * dt, 0.);
-    if (p.use_operator_splitting) {
+    if (Sw<K>::use_operator_splitting(p)) {
       double nVolfl = Tnfl * Wfl * Lfl; const double Mnew1_fl = (nVolfl / Volfl) * Mfl; dMb_fl = Mfl - Mnew1_fl;
       Lnfl = dmax(Lfl - Mv_fl * dt, 0.); Wnfl = dmax(Wfl - Mv_fl * dt, 0.);
       nVolfl = Tnfl * Wnfl * Lnfl; const double Mnew2_fl = (nVolfl / Volfl) * Mfl; dMv_fl = Mnew1_fl - Mnew2_fl;
@@ -254,9 +256,10 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   } else Mnew_fl = b.mass_of_fl_bits;
   // bergy bits IB:3071-3111
   double dMbitsE = 0., dMbitsM = 0., nMbits = b.mass_of_bits, dMbitsE_fl = 0., dMbitsM_fl = 0., nMbits_fl = b.mass_of_fl_bergy_bits;
-  if (p.bergy_bit_erosion_fraction > 0.) {
+  if (Sw<K>::bergy_bit_erosion_fraction(p) > 0.) {
+    const double bbef = Sw<K>::bergy_bit_erosion_fraction(p);
     const double Mbits = b.mass_of_bits;
-    dMbitsE = p.bergy_bit_erosion_fraction * dMe;
+    dMbitsE = bbef * dMe;
     nMbits = Mbits + dMbitsE;
     const double Lbits = dmin(dmin(dmin(L, W), T), 40.);
     const double Abits = (Mbits / p.rho_bergs) / Lbits;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
     if (Mnew == 0.) { dMbitsM = dMbitsM + nMbits; nMbits = 0.; }
     if (has_fl) {
       const double Mbits_fl = b.mass_of_fl_bergy_bits;
-      dMbitsE_fl = p.bergy_bit_erosion_fraction * dMe_fl;
+      dMbitsE_fl = bbef * dMe_fl;
       nMbits_fl = Mbits_fl + dMbitsE_fl;
       const double Lbits_fl = dmin(dmin(dmin(Lfl, Wfl), Tfl), 40.);
       const double Abits_fl = (Mbits_fl / p.rho_bergs) / Lbits_fl;
@@ -280,46 +283,48 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   }
   // per-cell accumulation IB:3114-3208
   const double area = cellv.area(), ms = b.mass_scaling;
+  const Rcp rarea = kid_rcp(area);
   const bool ok = active && (area != 0.);
-  const int dm = p.diag_mask;
+  const int dm = Sw<K>::diag_mask(p);
 #define KID_ACC(F, v) cell_add(acc, ncell, (F), c, (v), seg, ok)
-  double melt = (dM - (dMbitsE - dMbitsM) + dMfl - (dMbitsE_fl - dMbitsM_fl)) / dt;
-  KID_ACC(KID_A_FLOATING_MELT, melt / area * ms);
+  double melt = (dM - (dMbitsE - dMbitsM) + dMfl - (dMbitsE_fl - dMbitsM_fl)) * rdt;
+  KID_ACC(KID_A_FLOATING_MELT, melt * rarea * ms);
   if (dm & KID_DIAG_MELT_BY_CLASS) {
     const int kc = (lat < 0.) ? minloc_abs10(p.initial_mass_s, b.start_mass) : minloc_abs10(p.initial_mass_n, b.start_mass);
-    for (int q = 0; q < 10; ++q) KID_ACC(KID_A_MELT_BY_CLASS + q, (kc == q) ? melt / area * ms : 0.);
+    for (int q = 0; q < 10; ++q) KID_ACC(KID_A_MELT_BY_CLASS + q, (kc == q) ? melt * rarea * ms : 0.);
   }
   melt = melt * b.heat_density;
-  KID_ACC(KID_A_CALVING_HFLX, melt / area * ms);
+  KID_ACC(KID_A_CALVING_HFLX, melt * rarea * ms);
   {
-    const double h = wave_sum(ok ? melt * ms * dt : 0.);
-    if (__lane_id() == 0 && h != 0.) unsafeAtomicAdd(scal + KID_S_NET_HEAT_TO_OCEAN, h);
+    const double hv = ok ? melt * ms * dt : 0.;
+    if (__ballot(hv != 0.) != 0ull) {   // heat_density = 0 everywhere (every BASELINE config): nothing to sum
+      const double h = wave_sum(hv);
+      if (__lane_id() == 0 && h != 0.) unsafeAtomicAdd(scal + KID_S_NET_HEAT_TO_OCEAN, h);
+    }
   }
-  melt = dM / dt; KID_ACC(KID_A_BERG_MELT, melt / area * ms);
-  if (p.bergy_bit_erosion_fraction > 0.) {
-    melt = (dMbitsE + dMbitsE_fl) / dt; KID_ACC(KID_A_BERGY_SRC, melt / area * ms);
-    melt = (dMbitsM + dMbitsM_fl) / dt; KID_ACC(KID_A_BERGY_MELT, melt / area * ms);
+  melt = dM * rdt; KID_ACC(KID_A_BERG_MELT, melt * rarea * ms);
+  if (Sw<K>::bergy_bit_erosion_fraction(p) > 0.) {
+    melt = (dMbitsE + dMbitsE_fl) * rdt; KID_ACC(KID_A_BERGY_SRC, melt * rarea * ms);
+    melt = (dMbitsM + dMbitsM_fl) * rdt; KID_ACC(KID_A_BERGY_MELT, melt * rarea * ms);
   }
-  if (__ballot(has_fl && ok) != 0ull) { melt = dMfl / dt; KID_ACC(KID_A_FL_BITS_MELT, melt / area * ms); }
+  if (__ballot(has_fl && ok) != 0ull) { melt = dMfl * rdt; KID_ACC(KID_A_FL_BITS_MELT, melt * rarea * ms); }
   if (dm & (KID_DIAG_FL_PARENT_MELT | KID_DIAG_FL_CHILD_MELT | KID_DIAG_MELT_BUOY | KID_DIAG_MELT_EROS | KID_DIAG_MELT_CONV |
             KID_DIAG_MELT_BUOY_FL | KID_DIAG_MELT_EROS_FL | KID_DIAG_MELT_CONV_FL)) {
     const bool parent = fl_k >= 0;  // IB:3144; lanes contribute 0 to the planes of the other branch
-    const double s = 1. / dt;  // (x/dt written as in the reference below)
-    (void)s;
-    if (dm & KID_DIAG_FL_PARENT_MELT) KID_ACC(KID_A_FL_PARENT_MELT, parent ? ((dM - (dMbitsE - dMbitsM)) / dt) / area * ms : 0.);
+    if (dm & KID_DIAG_FL_PARENT_MELT) KID_ACC(KID_A_FL_PARENT_MELT, parent ? ((dM - (dMbitsE - dMbitsM)) * rdt) * rarea * ms : 0.);
     if (dm & KID_DIAG_FL_CHILD_MELT)
-      KID_ACC(KID_A_FL_CHILD_MELT, (parent ? ((dMfl - (dMbitsE_fl - dMbitsM_fl)) / dt) : ((dM - (dMbitsE - dMbitsM)) / dt)) / area * ms);
-    if (dm & KID_DIAG_MELT_BUOY) KID_ACC(KID_A_MELT_BUOY, parent ? (dMb / dt) / area * ms : 0.);
-    if (dm & KID_DIAG_MELT_EROS) KID_ACC(KID_A_MELT_EROS, parent ? (dMe / dt) / area * ms : 0.);
-    if (dm & KID_DIAG_MELT_CONV) KID_ACC(KID_A_MELT_CONV, parent ? (dMv / dt) / area * ms : 0.);
+      KID_ACC(KID_A_FL_CHILD_MELT, (parent ? ((dMfl - (dMbitsE_fl - dMbitsM_fl)) * rdt) : ((dM - (dMbitsE - dMbitsM)) * rdt)) * rarea * ms);
+    if (dm & KID_DIAG_MELT_BUOY) KID_ACC(KID_A_MELT_BUOY, parent ? (dMb * rdt) * rarea * ms : 0.);
+    if (dm & KID_DIAG_MELT_EROS) KID_ACC(KID_A_MELT_EROS, parent ? (dMe * rdt) * rarea * ms : 0.);
+    if (dm & KID_DIAG_MELT_CONV) KID_ACC(KID_A_MELT_CONV, parent ? (dMv * rdt) * rarea * ms : 0.);
     const bool flp = parent && (dMfl > 0);
-    if (dm & KID_DIAG_MELT_BUOY_FL) KID_ACC(KID_A_MELT_BUOY_FL, parent ? (flp ? (dMb_fl / dt) / area * ms : 0.) : (dMb / dt) / area * ms);
-    if (dm & KID_DIAG_MELT_EROS_FL) KID_ACC(KID_A_MELT_EROS_FL, parent ? (flp ? (dMe_fl / dt) / area * ms : 0.) : (dMe / dt) / area * ms);
-    if (dm & KID_DIAG_MELT_CONV_FL) KID_ACC(KID_A_MELT_CONV_FL, parent ? (flp ? (dMv_fl / dt) / area * ms : 0.) : (dMv / dt) / area * ms);
+    if (dm & KID_DIAG_MELT_BUOY_FL) KID_ACC(KID_A_MELT_BUOY_FL, parent ? (flp ? (dMb_fl * rdt) * rarea * ms : 0.) : (dMb * rdt) * rarea * ms);
+    if (dm & KID_DIAG_MELT_EROS_FL) KID_ACC(KID_A_MELT_EROS_FL, parent ? (flp ? (dMe_fl * rdt) * rarea * ms : 0.) : (dMe * rdt) * rarea * ms);
+    if (dm & KID_DIAG_MELT_CONV_FL) KID_ACC(KID_A_MELT_CONV_FL, parent ? (flp ? (dMv_fl * rdt) * rarea * ms : 0.) : (dMv * rdt) * rarea * ms);
   }
   unsigned nerr = (active && area == 0.) ? 1u : 0u;  // FATAL 'berg appears to have grounded!' IB:3207
-  if (p.allow_bergs_to_roll && N_bonds == 0.) rolling(p, Tn, Wn, Ln);
-  if (p.Iceberg_melt_without_decay) {  // IB:3214-3257
+  if (Sw<K>::allow_bergs_to_roll(p) && N_bonds == 0.) rolling<K>(p, Tn, Wn, Ln);
+  if (Sw<K>::Iceberg_melt_without_decay(p)) {  // IB:3214-3257
     if constexpr (TSPREAD) {  // IB:3219-3238
       BergThermo nb = b;
       nb.mass_of_fl_bits = Mnew_fl; nb.mass_of_fl_bergy_bits = nMbits_fl;
@@ -329,7 +334,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
         nb.M = M_edit; nb.mass_of_bits = nMbits; nb.mass_scaling = Mnew_fl * ms / M_edit; nb.L = Lnfl; nb.W = Wnfl; nb.T = Tnfl;
         nb.mass_of_fl_bits = 0.; nb.mass_of_fl_bergy_bits = 0.;
       }
-      spread_mass(g, p, cellv, nb, uvel, vvel, i, j, ts->xi, ts->yj, active && (Mnew > 0. || Mnew_fl > 0.), acc, ncell, seg, ts->footprint, ts->theta);
+      spread_mass<K>(g, p, cellv, nb, uvel, vvel, i, j, ts->xi, ts->yj, active && (Mnew > 0. || Mnew_fl > 0.), acc, ncell, seg, ts->footprint, ts->theta);
     }
     Mnew = M;
     b.fl_k = fl_k;
@@ -477,7 +482,7 @@ __device__ __noinline__ void hexagon_into_quadrants(const kid_params &p, double 
 // ---------------------------------------------------------------------------------------------------------
 // IB:3895-4133 spread_mass_across_ocean_cells + calculate_sum_over_bergs_diagnositcs (IB:5014-5071)
 // ---------------------------------------------------------------------------------------------------------
-template <class CELL>
+template <int K, class CELL>
 __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
                                             int i, int j, double x, double y, bool active, double *acc, size_t ncell, Seg &seg, bool footprint, double theta) {
   constexpr double rho_sw = 1035.;  // IB:3919 shadows the module's 1025
@@ -487,8 +492,8 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   const double Area = b.L * b.W, Tn = b.T, scaling = b.mass_scaling;
   double Mass_berg = b.M, Mfl = b.mass_of_fl_bits;
   const double Mbits_fl = b.mass_of_fl_bergy_bits;
-  if (p.grounding_fraction > 0.) {  // IB:3941-3950
-    const double Hocean = p.grounding_fraction * (g.ocean_depth[c] + g.ssh[c]);
+  if (Sw<K>::grounding_fraction(p) > 0.) {  // IB:3941-3950
+    const double Hocean = Sw<K>::grounding_fraction(p) * (g.ocean_depth[c] + g.ssh[c]);
     double Dn = (p.rho_bergs / rho_sw) * Tn;
     if (Dn > Hocean) Mass_berg = Mass_berg * dmin(1., Hocean / Dn);
     if (Mfl > 0.) {
@@ -499,14 +504,14 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   }
   Mass_berg = Mass_berg + Mfl;
   double Mass = (Mass_berg + b.mass_of_bits + Mbits_fl) * scaling;
-  if (p.clipping_depth > 0.) Mass = dmin(Mass, p.clipping_depth * a_ij * rho_sw);
+  if (Sw<K>::clipping_depth(p) > 0.) Mass = dmin(Mass, Sw<K>::clipping_depth(p) * a_ij * rho_sw);
   double w[9] = {0., 0., 0., 0., 1., 0., 0., 0., 0.};  // yDxL,yDxC,yDxR,yCxL,yCxC,yCxR,yUxL,yUxC,yUxR
   double fraction_used = 1.;
 #define KID_M(di, dj) cellv.msk((di), (dj))
-  if (!p.hexagonal_icebergs) {
+  if (!Sw<K>::hexagonal_icebergs(p)) {
     const double L = (a_ij > 0) ? dmin(sqrt(Area / a_ij), 1.0) : 1.;
     double xL, xR, xC, yD, yU, yC;
-    if (p.use_old_spreading) {
+    if (Sw<K>::use_old_spreading(p)) {
       xL = dmin(0.5, dmax(0., 0.5 - x)); xR = dmin(0.5, dmax(0., x - 0.5)); xC = dmax(0., 1. - (xL + xR));
       yD = dmin(0.5, dmax(0., 0.5 - y)); yU = dmin(0.5, dmax(0., y - 0.5)); yC = dmax(0., 1. - (yD + yU));
     } else {
@@ -538,7 +543,9 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   const int base[4] = {KID_A_MASS_ON_OCEAN, KID_A_AREA_ON_OCEAN, KID_A_UVEL_ON_OCEAN, KID_A_VVEL_ON_OCEAN};
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
-    if (__ballot(ok && w[s] != 0.) == 0ull) continue;  // slot unused by the whole wave
+    // slot unused by the whole wave: skipped (the plain build stages all nine, so that the number of staged values -- and
+    // with it the one place where the staging block is flushed -- is known at compile time)
+    if (K != 1 && __ballot(ok && w[s] != 0.) == 0ull) continue;
     cell_add(acc, ncell, base[0] + s, c, w[s] * vars[0] * Ifu, seg, ok);
     if (footprint) {  // wave-uniform: area / Uvel / Vvel footprints only when something downstream reads them
 #pragma unroll
@@ -547,36 +554,36 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   }
 }
 
-template <class CELL>
+template <int K = 0, class CELL>
 __device__ __forceinline__ void berg_diagnostics(const DevGrid &g, const kid_params &p, const CELL &cellv, const BergThermo &b, double uvel, double vvel,
                                                  int i, int j, bool active, double *acc, size_t ncell, Seg &seg) {
   const int c = g.idx(i, j);
   const double area = cellv.area(), ms = b.mass_scaling;
   const bool ok = active && (area > 0.);
-  const int dm = p.diag_mask;
+  const int dm = Sw<K>::diag_mask(p);
 #define KID_ACC(F, v) cell_add(acc, ncell, (F), c, (v), seg, ok)
   if (dm & KID_DIAG_VIRTUAL_AREA) {
     double Abits = 0., Abits_fl = 0., Abits_fl_bergy = 0.;
-    if (p.bergy_bit_erosion_fraction > 0.) Abits = (b.mass_of_bits / p.rho_bergs) / dmin(dmin(dmin(b.L, b.W), b.T), 40.);
+    if (Sw<K>::bergy_bit_erosion_fraction(p) > 0.) Abits = (b.mass_of_bits / p.rho_bergs) / dmin(dmin(dmin(b.L, b.W), b.T), 40.);
     if (p.fl_style == KID_FL_STYLE_FL_BITS) {
       double L_fl, W_fl, T_fl; fl_bits_dimensions(p, b.T, L_fl, W_fl, T_fl);
       Abits_fl = (b.mass_of_fl_bits / p.rho_bergs) / T_fl;
-      if (p.bergy_bit_erosion_fraction > 0.) Abits_fl_bergy = (b.mass_of_fl_bergy_bits / p.rho_bergs) / dmin(dmin(dmin(L_fl, W_fl), T_fl), 40.);
+      if (Sw<K>::bergy_bit_erosion_fraction(p) > 0.) Abits_fl_bergy = (b.mass_of_fl_bergy_bits / p.rho_bergs) / dmin(dmin(dmin(L_fl, W_fl), T_fl), 40.);
     }
     KID_ACC(KID_A_VIRTUAL_AREA, (b.W * b.L + Abits + Abits_fl + Abits_fl_bergy) * ms);
   }
   if (dm & (KID_DIAG_MASS | KID_DIAG_U_ICEBERG | KID_DIAG_V_ICEBERG)) KID_ACC(KID_A_MASS, b.M / area * ms);
   if (dm & KID_DIAG_U_ICEBERG) KID_ACC(KID_A_U_ICEBERG, ((b.M / area * ms) * uvel));
   if (dm & KID_DIAG_V_ICEBERG) KID_ACC(KID_A_V_ICEBERG, ((b.M / area * ms) * vvel));
-  if ((dm & KID_DIAG_BERGY_MASS) || p.add_weight_to_ocean) {
+  if ((dm & KID_DIAG_BERGY_MASS) || Sw<K>::add_weight_to_ocean(p)) {
     const double v = (b.mass_of_bits + b.mass_of_fl_bergy_bits) / area * ms;
     if (__ballot(ok && v != 0.) != 0ull) KID_ACC(KID_A_BERGY_MASS, v);
   }
-  if ((dm & KID_DIAG_FL_BITS_MASS) || p.add_weight_to_ocean) {
+  if ((dm & KID_DIAG_FL_BITS_MASS) || Sw<K>::add_weight_to_ocean(p)) {
     const double v = b.mass_of_fl_bits / area * ms;
     if (__ballot(ok && v != 0.) != 0ull) KID_ACC(KID_A_FL_BITS_MASS, v);
   }
-  if ((dm & KID_DIAG_FL_BERGY_BITS_MASS) || p.add_weight_to_ocean) {
+  if ((dm & KID_DIAG_FL_BERGY_BITS_MASS) || Sw<K>::add_weight_to_ocean(p)) {
     const double v = b.mass_of_fl_bergy_bits / area * ms;
     if (__ballot(ok && v != 0.) != 0ull) KID_ACC(KID_A_FL_BERGY_BITS_MASS, v);
   }

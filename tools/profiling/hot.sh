@@ -1,0 +1,8 @@
+#!/bin/bash
+# compile the hot build alone (tools/profiling/hot_only.hip) and print registers + static instruction mix; extra flags pass through
+cd "$(dirname "$0")/../.."
+mkdir -p /tmp/isa
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics --cuda-device-only -S -DKID_EXPERIMENTS -DKID_EXP_MARKERS \
+  -Rpass-analysis=kernel-resource-usage "$@" -o /tmp/isa/hot_only.s tools/profiling/hot_only.hip 2>&1 | grep -E "error|TotalSGPRs|VGPRs:|ScratchSize|Occupancy|SGPRs Spill|VGPRs Spill|LDS Size" | sed 's/.*remark: //' | tr '\n' ' '
+echo
+python3 tools/profiling/isa_stats.py /tmp/isa/hot_only.s

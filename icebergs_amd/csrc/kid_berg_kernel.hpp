@@ -18,6 +18,20 @@ struct BergPtrs {
   const double *orient;   // per-berg hexagon orientation from the bonds (IB:4004), or null: initial_orientation
 };
 struct Flags { int has_static, has_fl, store_env, footprint, no_diag; };   // no_diag: calculate_mass_on_ocean(with_diagnostics=.false.)  // footprint: area/Uvel/Vvel_on_ocean are read by somebody
+// The SoA arrays are reached through pointers read from a table in memory, which the compiler can only address as
+// generic (flat) pointers: flat loads count against the LDS counter as well as the memory counter, so every wait for an
+// LDS read would also wait for the loads still in flight.  These go through the global address space explicitly.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) int32_t gint32;
+__device__ __forceinline__ double ldg(const double *q, long long k) { return ((const gdouble *)q)[k]; }
+__device__ __forceinline__ int32_t ldg(const int32_t *q, long long k) { return ((const gint32 *)q)[k]; }
+// keep(x): an empty use of x.  The per-berg loads at the head of the kernel are written before the early exit of an
+// all-dead wave so that they are all in flight at once; values used on the live path only would be sunk below that branch
+// by the compiler, behind the wait for `alive` -- a second round trip to HBM per wave.  The dead path "uses" them too.
+__device__ __forceinline__ void keep(double x) { asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ void keep(int32_t x) { asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ void stg(double *q, long long k, double v) { ((gdouble *)q)[k] = v; }
+__device__ __forceinline__ void stg(int32_t *q, long long k, int32_t v) { ((gint32 *)q)[k] = v; }
 // the plain build (K = 1, kid_device.hpp) is launched only with all five flags zero
 template <int K> struct Fl {
 #define KID_X(name) static __device__ __forceinline__ int name(const Flags &f) { if constexpr (K == 1) return 0; else return f.name; }
@@ -65,18 +79,53 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
   const long long total = FAST ? redo.klen : (long long)(*redo.count);
   const long long bdim = FAST ? 256ll : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
-  for (long long tid = (long long)blockIdx.x * bdim + threadIdx.x; (FAST ? (tid == (long long)blockIdx.x * bdim + threadIdx.x) : (tid - threadIdx.x < total));
-       tid += (long long)gridDim.x * bdim) {
+  // (the hot build's "loop" visibly runs once: otherwise the compiler hoists the constants of the whole body out of it and
+  // holds -- or spills -- them in vector registers)
+  long long tid = (long long)blockIdx.x * bdim + threadIdx.x;
+  for (bool first = true; FAST ? first : (tid - threadIdx.x < total); first = false, tid += (long long)gridDim.x * bdim) {
   const bool inrange = tid < total;
   const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
-  bool was_alive = inrange && (b.i[KID_BI_ALIVE][kk] != 0);
-  if (FAST && redo.lane) { if (was_alive && redo.lane[kk] >= redo.step) was_alive = false; }
-  if (__ballot(was_alive) == 0ull) continue;  // wave-uniform; every other lane stays to the end (wave-level sums below)
+  // Every load of the step is issued here, back to back, before anything is used: `alive`, the lane stamp, the cell and
+  // the fields used to be three dependent round trips to HBM at the head of every wave (~15 % of its lifetime).
+  const int32_t alive_v = ldg(b.i[KID_BI_ALIVE], kk);
+  // (no branch around the lane-stamp load -- the join would wait for it: without stamps it re-reads `alive`)
+  const int32_t lane_v = FAST ? ldg(redo.lane ? (const int32_t *)redo.lane : (const int32_t *)b.i[KID_BI_ALIVE], kk) : 0;
+  BergDyn d;
+  d.ine = ldg(b.i[KID_BI_INE], kk); d.jne = ldg(b.i[KID_BI_JNE], kk);
+  d.xi = ldg(b.f[KID_B_XI], kk); d.yj = ldg(b.f[KID_B_YJ], kk);
+  d.lon = ldg(b.f[KID_B_LON], kk); d.lat = ldg(b.f[KID_B_LAT], kk);
+  d.uvel = ldg(b.f[KID_B_UVEL], kk); d.vvel = ldg(b.f[KID_B_VVEL], kk);
+  d.uvel_prev = 0.; d.vvel_prev = 0.;
+  d.axn = 0.; d.ayn = 0.; d.bxn = 0.; d.byn = 0.;
+  if (PH & PH_EVOLVE) {
+    d.axn = ldg(b.f[KID_B_AXN], kk); d.ayn = ldg(b.f[KID_B_AYN], kk);
+    if (!RK) { d.bxn = ldg(b.f[KID_B_BXN], kk); d.byn = ldg(b.f[KID_B_BYN], kk); }
+  }
+  BergThermo t;
+  t.M = ldg(b.f[KID_B_MASS], kk); t.T = ldg(b.f[KID_B_THICKNESS], kk); t.W = ldg(b.f[KID_B_WIDTH], kk); t.L = ldg(b.f[KID_B_LENGTH], kk);
+  t.n_bonds = Sw<K>::iceberg_bonds_on(p) ? ldg(b.i[KID_BI_N_BONDS], kk) : 0;
+  t.static_berg = Fl<K>::has_static(fl) ? ldg(b.f[KID_B_STATIC_BERG], kk) : 0.;
+  const bool halo = Fl<K>::has_static(fl) ? (ldg(b.f[KID_B_HALO_BERG], kk) >= 0.5) : false;
+  // The hot build of the fused RK4 step parks what only the thermodynamics needs in its wave's staging rows (idle until
+  // the first cell_add) instead of holding the registers -- or re-reading HBM -- across the RK4 loop.
+  constexpr bool SCATTER_ = (PH & (PH_THERMO | PH_SPREAD)) != 0;
+  constexpr bool PARK = FAST && SCATTER_ && RK && (PH & PH_EVOLVE) != 0;
+  double park_ms = 0., park_bits = 0., park_hd = 0.;
+  if constexpr (PARK) {
+    park_ms = ldg(b.f[KID_B_MASS_SCALING], kk); park_bits = ldg(b.f[KID_B_MASS_OF_BITS], kk);
+    park_hd = (PH & PH_THERMO) ? ldg(b.f[KID_B_HEAT_DENSITY], kk) : 0.;
+  }
+  bool was_alive = inrange && (alive_v != 0);
+  if (FAST && redo.lane) { if (was_alive && lane_v >= redo.step) was_alive = false; }
+  if (__ballot(was_alive) == 0ull) {  // wave-uniform; every other lane stays to the end (wave-level sums below)
+    keep(d.ine); keep(d.jne); keep(d.xi); keep(d.yj); keep(d.lon); keep(d.lat); keep(d.uvel); keep(d.vvel); keep(d.axn); keep(d.ayn);
+    keep(d.bxn); keep(d.byn); keep(t.M); keep(t.T); keep(t.W); keep(t.L); keep(t.n_bonds); keep(t.static_berg);
+    keep(park_ms); keep(park_bits); keep(park_hd);
+    continue;
+  }
   double *scal = acc + (size_t)KID_NACC * ncell;
 
-  BergDyn d;
-  d.ine = b.i[KID_BI_INE][kk]; d.jne = b.i[KID_BI_JNE][kk];
   // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
   Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);
   const lds_double *pk = nullptr;
@@ -100,23 +149,19 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     for (int r = 0; r < nstage; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
       const int c = seg.cell[r];
       if (c >= 0) {
-        wpk[r * PK_STRIDE + lane] = *reinterpret_cast<const double *>(s0.base + (long long)c * s0.stride);
-        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = *reinterpret_cast<const double *>(s1.base + (long long)c * s1.stride);
+        wpk[r * PK_STRIDE + lane] = *reinterpret_cast<const gdouble *>((const __attribute__((address_space(1))) char *)s0.base + (long long)c * s0.stride);
+        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = *reinterpret_cast<const gdouble *>((const __attribute__((address_space(1))) char *)s1.base + (long long)c * s1.stride);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     pk = wpk + (myrun < KID_MAXRUN ? myrun : 0) * PK_STRIDE;
   }
-  d.xi = b.f[KID_B_XI][kk]; d.yj = b.f[KID_B_YJ][kk];
-  d.lon = b.f[KID_B_LON][kk]; d.lat = b.f[KID_B_LAT][kk];
-  d.uvel = b.f[KID_B_UVEL][kk]; d.vvel = b.f[KID_B_VVEL][kk];
-  d.uvel_prev = 0.; d.vvel_prev = 0.;
-  BergThermo t;
-  t.alive = was_alive;
-  t.M = b.f[KID_B_MASS][kk]; t.T = b.f[KID_B_THICKNESS][kk]; t.W = b.f[KID_B_WIDTH][kk]; t.L = b.f[KID_B_LENGTH][kk];
-  t.n_bonds = Sw<K>::iceberg_bonds_on(p) ? b.i[KID_BI_N_BONDS][kk] : 0;
-  t.static_berg = Fl<K>::has_static(fl) ? b.f[KID_B_STATIC_BERG][kk] : 0.;
-  const bool halo = Fl<K>::has_static(fl) ? (b.f[KID_B_HALO_BERG][kk] >= 0.5) : false;
+  t.alive = was_alive;   // (after the hot build has handed the lanes of its surplus runs to the general build)
+  if constexpr (PARK) {
+    lds_double *row = seg.val + (int)__lane_id();
+    row[0 * KID_ROW] = t.M; row[1 * KID_ROW] = t.T; row[2 * KID_ROW] = t.W; row[3 * KID_ROW] = t.L;
+    row[4 * KID_ROW] = park_ms; row[5 * KID_ROW] = park_bits; row[6 * KID_ROW] = park_hd;
+  }
   Env e = {};
   unsigned tickets = 0u;
   int err = 0;
@@ -128,20 +173,24 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     if (PH & PH_INTERP) {  // IB:4673-4715
       if (was_alive && !halo) { interp_flds<K>(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e); env_dirty = true; }
     } else {  // stored environment (.not.old_interp_flds_order), IB:2039-2040
-      e.uo = b.f[KID_B_UO][kk]; e.vo = b.f[KID_B_VO][kk]; e.ui = b.f[KID_B_UI][kk]; e.vi = b.f[KID_B_VI][kk];
-      e.ua = b.f[KID_B_UA][kk]; e.va = b.f[KID_B_VA][kk]; e.ssh_x = b.f[KID_B_SSH_X][kk]; e.ssh_y = b.f[KID_B_SSH_Y][kk];
-      e.sst = b.f[KID_B_SST][kk]; e.sss = b.f[KID_B_SSS][kk]; e.cn = b.f[KID_B_CN][kk]; e.hi = b.f[KID_B_HI][kk]; e.od = b.f[KID_B_OD][kk];
+      e.uo = ldg(b.f[KID_B_UO], kk); e.vo = ldg(b.f[KID_B_VO], kk); e.ui = ldg(b.f[KID_B_UI], kk); e.vi = ldg(b.f[KID_B_VI], kk);
+      e.ua = ldg(b.f[KID_B_UA], kk); e.va = ldg(b.f[KID_B_VA], kk); e.ssh_x = ldg(b.f[KID_B_SSH_X], kk); e.ssh_y = ldg(b.f[KID_B_SSH_Y], kk);
+      e.sst = ldg(b.f[KID_B_SST], kk); e.sss = ldg(b.f[KID_B_SSS], kk); e.cn = ldg(b.f[KID_B_CN], kk); e.hi = ldg(b.f[KID_B_HI], kk); e.od = ldg(b.f[KID_B_OD], kk);
     }
   }
 
   if (PH & PH_EVOLVE) {  // IB:7081-7179
-    d.axn = b.f[KID_B_AXN][kk]; d.ayn = b.f[KID_B_AYN][kk];
-    if (!RK) { d.bxn = b.f[KID_B_BXN][kk]; d.byn = b.f[KID_B_BYN][kk]; } else { d.bxn = 0.; d.byn = 0.; }
     const bool moves = was_alive && (t.static_berg < 0.5);
     if (moves) {
       const BergGeom bg{t.M, t.T, t.W, t.L, t.n_bonds};
       if (RK) rk4_step<OLD_ORDER, FAST, K>(g, p, bg, e, d, tickets, err, bail, pk);
       else verlet_step<OLD_ORDER, FAST, K>(g, p, bg, e, d, tickets, err, bail, pk);
+      if constexpr (PARK) {
+        KID_PHASE_FENCE();
+        const lds_double *row = seg.val + (int)__lane_id();
+        t.M = row[0 * KID_ROW]; t.T = row[1 * KID_ROW]; t.W = row[2 * KID_ROW]; t.L = row[3 * KID_ROW];
+        park_ms = row[4 * KID_ROW]; park_bits = row[5 * KID_ROW]; park_hd = row[6 * KID_ROW];
+      }
       if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
         const int slot = atomicAdd(redo.count, 1);
         redo.list[slot] = (int)kk;
@@ -164,17 +213,17 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
               double xi2, yj2;
               if (!pos_within_cell<false>(g, p, cell2, d.lon, d.lat, i2, d.jne, xi2, yj2, perr, pbail)) err = 1;  // not in the cell one period away: 'can not find a cell to place berg in!' FW:3660
               d.ine = i2; d.xi = xi2; d.yj = yj2;
-              b.f[KID_B_UVEL_OLD][kk] = d.uvel; b.f[KID_B_VVEL_OLD][kk] = d.vvel; b.f[KID_B_LON_OLD][kk] = d.lon; b.f[KID_B_LAT_OLD][kk] = d.lat;
+              stg(b.f[KID_B_UVEL_OLD], kk, d.uvel); stg(b.f[KID_B_VVEL_OLD], kk, d.vvel); stg(b.f[KID_B_LON_OLD], kk, d.lon); stg(b.f[KID_B_LAT_OLD], kk, d.lat);
               back = true;
             }
           }
           if (!back) t.alive = false;
         }
-        b.f[KID_B_LON][kk] = d.lon; b.f[KID_B_LAT][kk] = d.lat; b.f[KID_B_UVEL][kk] = d.uvel; b.f[KID_B_VVEL][kk] = d.vvel;
-        b.f[KID_B_AXN][kk] = d.axn; b.f[KID_B_AYN][kk] = d.ayn; b.f[KID_B_BXN][kk] = d.bxn; b.f[KID_B_BYN][kk] = d.byn;
-        b.f[KID_B_XI][kk] = d.xi; b.f[KID_B_YJ][kk] = d.yj;
-        b.i[KID_BI_INE][kk] = d.ine; b.i[KID_BI_JNE][kk] = d.jne;
-        if (!RK) { b.f[KID_B_UVEL_PREV][kk] = d.uvel_prev; b.f[KID_B_VVEL_PREV][kk] = d.vvel_prev; }
+        stg(b.f[KID_B_LON], kk, d.lon); stg(b.f[KID_B_LAT], kk, d.lat); stg(b.f[KID_B_UVEL], kk, d.uvel); stg(b.f[KID_B_VVEL], kk, d.vvel);
+        stg(b.f[KID_B_AXN], kk, d.axn); stg(b.f[KID_B_AYN], kk, d.ayn); stg(b.f[KID_B_BXN], kk, d.bxn); stg(b.f[KID_B_BYN], kk, d.byn);
+        stg(b.f[KID_B_XI], kk, d.xi); stg(b.f[KID_B_YJ], kk, d.yj);
+        stg(b.i[KID_BI_INE], kk, d.ine); stg(b.i[KID_BI_JNE], kk, d.jne);
+        if (!RK) { stg(b.f[KID_B_UVEL_PREV], kk, d.uvel_prev); stg(b.f[KID_B_VVEL_PREV], kk, d.vvel_prev); }
       }
     }
     const unsigned long long bt = __ballot(tickets != 0u);
@@ -193,7 +242,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     if (was_alive && !skipped && t.alive) {
       const FlChildCtx cx{redo.fl_cursor, redo.fl_counter, n, redo.fl_capacity, redo.fl_iNg};
       footloose_one(g, p, b, cx, kk, acc, ncell, scal);
-      t.M = b.f[KID_B_MASS][kk]; t.T = b.f[KID_B_THICKNESS][kk]; t.W = b.f[KID_B_WIDTH][kk]; t.L = b.f[KID_B_LENGTH][kk];
+      t.M = ldg(b.f[KID_B_MASS], kk); t.T = ldg(b.f[KID_B_THICKNESS], kk); t.W = ldg(b.f[KID_B_WIDTH], kk); t.L = ldg(b.f[KID_B_LENGTH], kk);
     }
   }
 
@@ -201,14 +250,17 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     const bool active = t.alive && !skipped;
     if (!FAST) seg = make_runs(active ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);  // cells may have changed
     const typename CellOf<FAST>::type cellv = CellOf<FAST>::make(g, pk, d.ine, d.jne);
-    t.mass_scaling = b.f[KID_B_MASS_SCALING][kk];
-    t.mass_of_bits = b.f[KID_B_MASS_OF_BITS][kk];
-    t.heat_density = (PH & PH_THERMO) ? b.f[KID_B_HEAT_DENSITY][kk] : 0.;
+    if constexpr (PARK) { t.mass_scaling = park_ms; t.mass_of_bits = park_bits; t.heat_density = park_hd; }
+    else {
+      t.mass_scaling = ldg(b.f[KID_B_MASS_SCALING], kk);
+      t.mass_of_bits = ldg(b.f[KID_B_MASS_OF_BITS], kk);
+      t.heat_density = (PH & PH_THERMO) ? ldg(b.f[KID_B_HEAT_DENSITY], kk) : 0.;
+    }
     if (Fl<K>::has_fl(fl)) {
-      t.mass_of_fl_bits = b.f[KID_B_MASS_OF_FL_BITS][kk]; t.mass_of_fl_bergy_bits = b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk];
-      t.fl_k = b.f[KID_B_FL_K][kk];
+      t.mass_of_fl_bits = ldg(b.f[KID_B_MASS_OF_FL_BITS], kk); t.mass_of_fl_bergy_bits = ldg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk);
+      t.fl_k = ldg(b.f[KID_B_FL_K], kk);
     } else { t.mass_of_fl_bits = 0.; t.mass_of_fl_bergy_bits = 0.; t.fl_k = 0.; }
-    t.start_mass = (Sw<K>::diag_mask(p) & KID_DIAG_MELT_BY_CLASS) ? b.f[KID_B_START_MASS][kk] : 0.;
+    t.start_mass = (Sw<K>::diag_mask(p) & KID_DIAG_MELT_BY_CLASS) ? ldg(b.f[KID_B_START_MASS], kk) : 0.;
     t.start_year = 0; t.start_day = 0.;
     if (PH & PH_THERMO) {
       if (!OLD_ORDER && (PH & PH_EVOLVE) && (PH & PH_INTERP)) {  // fused step: interp_gridded_fields_to_bergs again at the new position, IB:5473
@@ -227,14 +279,14 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
         thermodynamics<true, K>(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal, &ts);
       } else thermodynamics<false, K>(g, p, cellv, t, e, d.uvel, d.vvel, d.lat, d.ine, d.jne, active, acc, ncell, seg, scal);
       if (active) {
-        b.f[KID_B_MASS][kk] = t.M; b.f[KID_B_THICKNESS][kk] = t.T; b.f[KID_B_WIDTH][kk] = t.W; b.f[KID_B_LENGTH][kk] = t.L;
-        if (t.mass_of_bits != before.mass_of_bits) b.f[KID_B_MASS_OF_BITS][kk] = t.mass_of_bits;
+        stg(b.f[KID_B_MASS], kk, t.M); stg(b.f[KID_B_THICKNESS], kk, t.T); stg(b.f[KID_B_WIDTH], kk, t.W); stg(b.f[KID_B_LENGTH], kk, t.L);
+        if (t.mass_of_bits != before.mass_of_bits) stg(b.f[KID_B_MASS_OF_BITS], kk, t.mass_of_bits);
         if (Fl<K>::has_fl(fl)) {
-          b.f[KID_B_MASS_OF_FL_BITS][kk] = t.mass_of_fl_bits; b.f[KID_B_MASS_OF_FL_BERGY_BITS][kk] = t.mass_of_fl_bergy_bits;
-          b.f[KID_B_FL_K][kk] = t.fl_k;
+          stg(b.f[KID_B_MASS_OF_FL_BITS], kk, t.mass_of_fl_bits); stg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk, t.mass_of_fl_bergy_bits);
+          stg(b.f[KID_B_FL_K], kk, t.fl_k);
           if (t.mass_scaling != before.mass_scaling) {  // converted to a footloose child (IB:3272-3289)
-            b.f[KID_B_MASS_SCALING][kk] = t.mass_scaling;
-            b.i[KID_BI_START_YEAR][kk] = t.start_year; b.f[KID_B_START_DAY][kk] = t.start_day;
+            stg(b.f[KID_B_MASS_SCALING], kk, t.mass_scaling);
+            stg(b.i[KID_BI_START_YEAR], kk, t.start_year); stg(b.f[KID_B_START_DAY], kk, t.start_day);
           }
         }
       }
@@ -253,12 +305,12 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   }
 
   if (was_alive && !skipped) {
-    if (!t.alive) b.i[KID_BI_ALIVE][kk] = 0;
+    if (!t.alive) stg(b.i[KID_BI_ALIVE], kk, 0);
     if (env_dirty && Fl<K>::store_env(fl)) {
-      b.f[KID_B_UO][kk] = e.uo; b.f[KID_B_VO][kk] = e.vo; b.f[KID_B_UI][kk] = e.ui; b.f[KID_B_VI][kk] = e.vi;
-      b.f[KID_B_UA][kk] = e.ua; b.f[KID_B_VA][kk] = e.va; b.f[KID_B_SSH_X][kk] = e.ssh_x; b.f[KID_B_SSH_Y][kk] = e.ssh_y;
-      b.f[KID_B_SST][kk] = e.sst; b.f[KID_B_SSS][kk] = e.sss; b.f[KID_B_CN][kk] = e.cn; b.f[KID_B_HI][kk] = e.hi;
-      if (PH & PH_INTERP) b.f[KID_B_OD][kk] = e.od;
+      stg(b.f[KID_B_UO], kk, e.uo); stg(b.f[KID_B_VO], kk, e.vo); stg(b.f[KID_B_UI], kk, e.ui); stg(b.f[KID_B_VI], kk, e.vi);
+      stg(b.f[KID_B_UA], kk, e.ua); stg(b.f[KID_B_VA], kk, e.va); stg(b.f[KID_B_SSH_X], kk, e.ssh_x); stg(b.f[KID_B_SSH_Y], kk, e.ssh_y);
+      stg(b.f[KID_B_SST], kk, e.sst); stg(b.f[KID_B_SSS], kk, e.sss); stg(b.f[KID_B_CN], kk, e.cn); stg(b.f[KID_B_HI], kk, e.hi);
+      if (PH & PH_INTERP) stg(b.f[KID_B_OD], kk, e.od);
     }
   }
   const unsigned long long be = __ballot(err != 0);

@@ -448,7 +448,11 @@ struct BergGeom { double M, T, W, L; int n_bonds; };
 // coefficients, the grounding drag, the size factors of the wave-radiation force (IB:2050-2130).  A berg of the hot
 // build stays in its cell, so these are the same in all four RK4 stages and are evaluated once per step (the general
 // build, whose berg may change cells between stages, evaluates them per stage) -- the same expressions either way.
+#ifdef KID_EXACT_MATH
 struct AccelPre { double c_gnd, c_ocn, c_atm, c_ice, pref_wave, F, WL2, L; Rcp rWpL; };
+#else
+struct AccelPre { double c_gnd, c_ocn, c_atm, c_ice, wave_q, F, L; };   // wave_q = 0.5 rho_sw/M * g * 2WL/(W+L): one register instead of three
+#endif
 template <int K = 0>
 __device__ __forceinline__ AccelPre accel_pre(const DevGrid &g, const kid_params &p, const BergGeom &bg, double hi_cell, double od) {
   AccelPre a;
@@ -473,8 +477,13 @@ __device__ __forceinline__ AccelPre accel_pre(const DevGrid &g, const kid_params
   a.c_ocn = RHO_SEAWATER * rM * p.ocean_drag_scale * (0.5 * CD_WV * dragfrac * W * (D_hi) + CD_WH * W * L);
   a.c_atm = RHO_AIR * rM * (0.5 * CD_AV * dragfrac * W * F + CD_AH * W * L);
   a.c_ice = (fabs(hi) == 0.) ? 0. : RHO_ICE * rM * (0.5 * CD_IV * dragfrac * W * hi);
+#ifdef KID_EXACT_MATH
   a.pref_wave = (0.5 * RHO_SEAWATER) * rM;
   a.F = F; a.WL2 = 2. * W * L; a.L = L; a.rWpL = kid_rcp(W + L);
+#else
+  a.wave_q = (0.5 * RHO_SEAWATER) * rM * GRAVITY * (2. * W * L) * kid_rcp(W + L);
+  a.F = F; a.L = L;
+#endif
   return a;
 }
 
@@ -495,7 +504,11 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   const double ampl = 0.5 * 0.02025 * wmod, Lwavelength = 0.32 * wmod;
   const double Lcutoff = 0.125 * Lwavelength, Ltop = 0.25 * Lwavelength;
   const double Cr = 0.06 * dmin(dmax(0., kid_div(ap.L - Lcutoff, (Ltop - Lcutoff) + 1.e-30)), 1.);
+#ifdef KID_EXACT_MATH
   double wave_rad = ap.pref_wave * Cr * GRAVITY * ampl * dmin(ampl, ap.F) * ap.WL2 * ap.rWpL;
+#else
+  double wave_rad = ap.wave_q * Cr * ampl * dmin(ampl, ap.F);
+#endif
   wmod = sqrt(ua * ua + va * va);
   if (wmod != 0.) { const Rcp rw = kid_rcp(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
   double c_ice = ap.c_ice;
@@ -758,10 +771,17 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
       rotvec_to_tang(p, lon_s, ax, ay, qax, qay);
       rotvec_to_tang(p, lon_s, axn_s, ayn_s, qaxn, qayn);
     }
+#ifdef KID_EXACT_MATH
     if (s == 0)      { Au = qu; Av = qv; Aax = qax; Aay = qay; Aaxn = qaxn; Aayn = qayn; }
     else if (s == 1) { Bu = qu; Bv = qv; Bax = qax; Bay = qay; Baxn = qaxn; Bayn = qayn; }
     else if (s == 2) { Bu = Bu + qu; Bv = Bv + qv; Bax = Bax + qax; Bay = Bay + qay; Baxn = Baxn + qaxn; Bayn = Bayn + qayn; }
     else             { Au = Au + qu; Av = Av + qv; Aax = Aax + qax; Aay = Aay + qay; Aaxn = Aaxn + qaxn; Aayn = Aayn + qayn; }
+#else
+    {  // one running sum q1 + 2 q2 + 2 q3 + q4 per quantity (kept in A, B stays 0): half the registers of the (q1+q4), (q2+q3) pairs
+      const double wq = (s == 0 || s == 3) ? 1. : 2.;
+      Au = Au + wq * qu; Av = Av + wq * qv; Aax = Aax + wq * qax; Aay = Aay + wq * qay; Aaxn = Aaxn + wq * qaxn; Aayn = Aayn + wq * qayn;
+    }
+#endif
     if (s < 3) {  // X_{k+1} = X1 + c V_k ; V_{k+1} = V1 + c A_k   (c = dt/2, dt/2, dt)
       const double c = (s < 2) ? dt_2 : dt;
       if (on_tang) {

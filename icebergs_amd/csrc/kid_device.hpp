@@ -74,6 +74,30 @@ __device__ __forceinline__ double kid_div(double a, double b) {  // one more cor
   return __builtin_fma(__builtin_fma(-b, q, a), r.r, q);
 }
 #endif
+// a*b + c.  The library is compiled with -ffp-contract=off and stays so: left to the compiler, contraction differs between
+// the hot and the general build of the same source line, and a berg's result would depend on which of them stepped it.
+// Where the hot loop spends its multiplies and adds (bilinear interpolation, rotations, sums of squares) the fused form is
+// spelled out instead -- the same instruction in every build -- unless -DKID_EXACT_MATH.
+#ifdef KID_EXACT_MATH
+__device__ __forceinline__ double kid_fma(double a, double b, double c) { return a * b + c; }
+#else
+__device__ __forceinline__ double kid_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#endif
+// Square root of a speed or a length: one Goldschmidt step on v_rsq_f64 (~23 bits) and one residual correction, <= 1 ulp;
+// without the range scaling of the IEEE expansion (the arguments are sums of squares of velocities, areas, ...: far from the
+// ends of the exponent range) -- 11 instructions instead of 17.  0 and negative arguments as sqrt() treats them.
+#ifdef KID_EXACT_MATH
+__device__ __forceinline__ double kid_sqrt(double x) { return sqrt(x); }
+#else
+__device__ __forceinline__ double kid_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return (x > 0.) ? g : ((x == 0.) ? x : __builtin_nan(""));
+}
+#endif
 
 // reference module constants, IB:68-80
 constexpr double RHO_ICE = 916.7, RHO_AIR = 1.1, RHO_SEAWATER = 1025.0, GRAVITY = 9.8;
@@ -298,7 +322,7 @@ __device__ __forceinline__ bool calc_xiyj(double x1, double x2, double x3, doubl
   if (fabs(a) > 1.e-12) {
     const double d = 0.25 * (b * b) - a * c;
     if (d >= 0.) {
-      const double sd = sqrt(d);
+      const double sd = kid_sqrt(d);
       const Rcp ra = kid_rcp(a);
       const double yy1 = -(0.5 * b + sd) * ra, yy2 = -(0.5 * b - sd) * ra;
       yj = (fabs(yy1 - 0.5) < fabs(yy2 - 0.5)) ? yy1 : yy2;
@@ -392,14 +416,17 @@ __device__ __forceinline__ void bilin_lonlat(const DevGrid &g, const kid_params 
 // ---------------------------------------------------------------------------------------------------------
 // IB:4718-4900 interp_flds (non-MTS; tidal_drift = 0)
 // ---------------------------------------------------------------------------------------------------------
+// need_ice = false (wave-uniform): no berg of the wave sits in a cell with sea ice (hi = 0: c_ice = 0, IB:2129), so the ice
+// velocity multiplies 0 wherever it goes and is not interpolated -- bitwise the same accelerations
 template <int K = 0, class CELL>
-__device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cell, double xi, double yj, Env &e) {
+__device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cell, double xi, double yj, Env &e, bool need_ice = true) {
   double wx1, wx0, wy1, wy0;  // weights of columns i / i-1 and rows j / j-1 (FW:7081-7087)
   if (Sw<K>::old_bug_bilin(p)) { wx1 = 1. - xi; wx0 = xi; wy1 = 1. - yj; wy0 = yj; }
   else { wx1 = xi; wx0 = 1. - xi; wy1 = yj; wy0 = 1. - yj; }
-#define KID_BIL(f) ((cell.vel(3, f) * wx1 + cell.vel(2, f) * wx0) * wy1 + (cell.vel(1, f) * wx1 + cell.vel(0, f) * wx0) * wy0)
+#define KID_BIL(f) kid_fma(kid_fma(cell.vel(3, f), wx1, cell.vel(2, f) * wx0), wy1, kid_fma(cell.vel(1, f), wx1, cell.vel(0, f) * wx0) * wy0)
   const double cos_rot = KID_BIL(0), sin_rot = KID_BIL(1);
-  double uo = KID_BIL(2), vo = KID_BIL(3), ui = KID_BIL(4), vi = KID_BIL(5), ua = KID_BIL(6), va = KID_BIL(7);
+  double uo = KID_BIL(2), vo = KID_BIL(3), ui = 0., vi = 0., ua = KID_BIL(6), va = KID_BIL(7);
+  if (need_ice) { ui = KID_BIL(4); vi = KID_BIL(5); }
 #undef KID_BIL
   if (Sw<K>::coastal_drift(p) > 0.) {  // IB:4769-4776
     const double cd = Sw<K>::coastal_drift(p);
@@ -412,27 +439,27 @@ __device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cel
   // sea-surface slope from the hoisted per-cell stencils (IB:4830-4860)
   double hxp, hxm;
   if (yj >= 0.5) {
-    hxp = (yj - 0.5) * cell.ddx(0) + (1.5 - yj) * cell.ddx(1);
-    hxm = (yj - 0.5) * cell.ddx(3) + (1.5 - yj) * cell.ddx(4);
+    hxp = kid_fma(yj - 0.5, cell.ddx(0), (1.5 - yj) * cell.ddx(1));
+    hxm = kid_fma(yj - 0.5, cell.ddx(3), (1.5 - yj) * cell.ddx(4));
   } else {
-    hxp = (yj + 0.5) * cell.ddx(1) + (0.5 - yj) * cell.ddx(2);
-    hxm = (yj + 0.5) * cell.ddx(4) + (0.5 - yj) * cell.ddx(5);
+    hxp = kid_fma(yj + 0.5, cell.ddx(1), (0.5 - yj) * cell.ddx(2));
+    hxm = kid_fma(yj + 0.5, cell.ddx(4), (0.5 - yj) * cell.ddx(5));
   }
-  double ssh_x = xi * hxp + (1. - xi) * hxm;
+  double ssh_x = kid_fma(xi, hxp, (1. - xi) * hxm);
   if (xi >= 0.5) {
-    hxp = (xi - 0.5) * cell.ddy(0) + (1.5 - xi) * cell.ddy(1);
-    hxm = (xi - 0.5) * cell.ddy(3) + (1.5 - xi) * cell.ddy(4);
+    hxp = kid_fma(xi - 0.5, cell.ddy(0), (1.5 - xi) * cell.ddy(1));
+    hxm = kid_fma(xi - 0.5, cell.ddy(3), (1.5 - xi) * cell.ddy(4));
   } else {
-    hxp = (xi + 0.5) * cell.ddy(1) + (0.5 - xi) * cell.ddy(2);
-    hxm = (xi + 0.5) * cell.ddy(4) + (0.5 - xi) * cell.ddy(5);
+    hxp = kid_fma(xi + 0.5, cell.ddy(1), (0.5 - xi) * cell.ddy(2));
+    hxm = kid_fma(xi + 0.5, cell.ddy(4), (0.5 - xi) * cell.ddy(5));
   }
-  double ssh_y = yj * hxp + (1. - yj) * hxm;
+  double ssh_y = kid_fma(yj, hxp, (1. - yj) * hxm);
   // rotate to lat-lon (IB:4953-4967)
   double t;
-  t = uo; uo = cos_rot * t + sin_rot * vo; vo = cos_rot * vo - sin_rot * t;
-  t = ui; ui = cos_rot * t + sin_rot * vi; vi = cos_rot * vi - sin_rot * t;
-  t = ua; ua = cos_rot * t + sin_rot * va; va = cos_rot * va - sin_rot * t;
-  t = ssh_x; ssh_x = cos_rot * t + sin_rot * ssh_y; ssh_y = cos_rot * ssh_y - sin_rot * t;
+  t = uo; uo = kid_fma(cos_rot, t, sin_rot * vo); vo = kid_fma(cos_rot, vo, -(sin_rot * t));
+  if (need_ice) { t = ui; ui = kid_fma(cos_rot, t, sin_rot * vi); vi = kid_fma(cos_rot, vi, -(sin_rot * t)); }
+  t = ua; ua = kid_fma(cos_rot, t, sin_rot * va); va = kid_fma(cos_rot, va, -(sin_rot * t));
+  t = ssh_x; ssh_x = kid_fma(cos_rot, t, sin_rot * ssh_y); ssh_y = kid_fma(cos_rot, ssh_y, -(sin_rot * t));
   if (ssh_x != ssh_x) ssh_x = 0.;
   if (ssh_y != ssh_y) ssh_y = 0.;
   e.uo = uo; e.vo = vo; e.ui = ui; e.vi = vi; e.ua = ua; e.va = va; e.ssh_x = ssh_x; e.ssh_y = ssh_y;
@@ -494,13 +521,13 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
                                       unsigned &tickets) {
   // RK: alpha=0, C_N=0, predictive-corrective per namelist; Verlet: alpha=C_N=1, predictive-corrective forced (IB:2002-2013)
   const bool new_pc = RK ? (Sw<K>::use_new_predictive_corrective(p) != 0) : true;
-  const double u_star = uvel0 + (axn * (dt / 2.)), v_star = vvel0 + (ayn * (dt / 2.));
+  const double u_star = kid_fma(axn, dt / 2., uvel0), v_star = kid_fma(ayn, dt / 2., vvel0);
   const double uo = e.uo, vo = e.vo, ui = e.ui, vi = e.vi, ua = e.ua, va = e.va;
   const double f_cori = (2. * p.omega) * sin_lat;  // IB:2043-2047, the caller picks lat or lat_ref
   const double c_gnd = ap.c_gnd, c_ocn = ap.c_ocn, c_atm = ap.c_atm;
   // wave radiation IB:2085-2102
   double uwave = ua - uo, vwave = va - vo;
-  double wmod = uwave * uwave + vwave * vwave;
+  double wmod = kid_fma(uwave, uwave, vwave * vwave);
   const double ampl = 0.5 * 0.02025 * wmod, Lwavelength = 0.32 * wmod;
   const double Lcutoff = 0.125 * Lwavelength, Ltop = 0.25 * Lwavelength;
   const double Cr = 0.06 * dmin(dmax(0., kid_div(ap.L - Lcutoff, (Ltop - Lcutoff) + 1.e-30)), 1.);
@@ -509,7 +536,7 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
 #else
   double wave_rad = ap.wave_q * Cr * ampl * dmin(ampl, ap.F);
 #endif
-  wmod = sqrt(ua * ua + va * va);
+  wmod = kid_sqrt(kid_fma(ua, ua, va * va));
   if (wmod != 0.) { const Rcp rw = kid_rcp(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
   double c_ice = ap.c_ice;
   if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.;
@@ -524,9 +551,9 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   // speeds are, so its three square roots per pass are skipped -- bitwise the same result
   const bool any_ice = __ballot(c_ice != 0.) != 0ull;
   if (new_pc) {
-    s0o = sqrt((uvel0 - uo) * (uvel0 - uo) + (vvel0 - vo) * (vvel0 - vo));
-    s0a = sqrt((uvel0 - ua) * (uvel0 - ua) + (vvel0 - va) * (vvel0 - va));
-    if (any_ice) s0i = sqrt((uvel0 - ui) * (uvel0 - ui) + (vvel0 - vi) * (vvel0 - vi));
+    s0o = kid_sqrt(kid_fma((uvel0 - uo), (uvel0 - uo), (vvel0 - vo) * (vvel0 - vo)));
+    s0a = kid_sqrt(kid_fma((uvel0 - ua), (uvel0 - ua), (vvel0 - va) * (vvel0 - va)));
+    if (any_ice) s0i = kid_sqrt(kid_fma((uvel0 - ui), (uvel0 - ui), (vvel0 - vi) * (vvel0 - vi)));
   }
   const double A12_0 = RK ? -0. * dt * f_cori : (-1. * dt * f_cori) / 2.;  // IB:2244-2251 (alpha, C_N)
   const double A21_0 = RK ? 0. * dt * f_cori : (1. * dt * f_cori) / 2.;
@@ -535,32 +562,32 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   for (int itloop = 1; itloop <= 2; ++itloop) {  // IB:2183-2277
     double drag_ocn, drag_atm, drag_ice;
     if (new_pc) {
-      drag_ocn = c_ocn * 0.5 * (sqrt((uveln - uo) * (uveln - uo) + (vveln - vo) * (vveln - vo)) + s0o);
-      drag_atm = c_atm * 0.5 * (sqrt((uveln - ua) * (uveln - ua) + (vveln - va) * (vveln - va)) + s0a);
-      drag_ice = any_ice ? c_ice * 0.5 * (sqrt((uveln - ui) * (uveln - ui) + (vveln - vi) * (vveln - vi)) + s0i) : 0.;
+      drag_ocn = c_ocn * 0.5 * (kid_sqrt(kid_fma((uveln - uo), (uveln - uo), (vveln - vo) * (vveln - vo))) + s0o);
+      drag_atm = c_atm * 0.5 * (kid_sqrt(kid_fma((uveln - ua), (uveln - ua), (vveln - va) * (vveln - va))) + s0a);
+      drag_ice = any_ice ? c_ice * 0.5 * (kid_sqrt(kid_fma((uveln - ui), (uveln - ui), (vveln - vi) * (vveln - vi))) + s0i) : 0.;
     } else {
       const double us = 0.5 * (uveln + uvel), vs = 0.5 * (vveln + vvel);
-      drag_ocn = c_ocn * sqrt((us - uo) * (us - uo) + (vs - vo) * (vs - vo));
-      drag_atm = c_atm * sqrt((us - ua) * (us - ua) + (vs - va) * (vs - va));
-      drag_ice = any_ice ? c_ice * sqrt((us - ui) * (us - ui) + (vs - vi) * (vs - vi)) : 0.;
+      drag_ocn = c_ocn * kid_sqrt(kid_fma((us - uo), (us - uo), (vs - vo) * (vs - vo)));
+      drag_atm = c_atm * kid_sqrt(kid_fma((us - ua), (us - ua), (vs - va) * (vs - va)));
+      drag_ice = any_ice ? c_ice * kid_sqrt(kid_fma((us - ui), (us - ui), (vs - vi) * (vs - vi))) : 0.;
     }
     const double drag_gnd = c_gnd;
     double RHS_x = (axn_l / 2) + bxn_l, RHS_y = (ayn_l / 2) + byn_l;
     RHS_x = RHS_x - drag_ocn * (u_star - uo) - drag_atm * (u_star - ua) - drag_ice * (u_star - ui) - drag_gnd * u_star;  // beta=1
     RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va) - drag_ice * (v_star - vi) - drag_gnd * v_star;
     const double lambda = drag_ocn + drag_atm + drag_ice + drag_gnd;
-    const double A11 = 1. + 1.0 * dt * lambda, A22 = 1. + 1.0 * dt * lambda;
+    const double A11 = kid_fma(dt, lambda, 1.), A22 = A11;
     const double detA = 1. * kid_rcp((A11 * A22) - (A12_0 * A21_0));
-    ax = detA * (A22 * RHS_x - A12_0 * RHS_y);
-    ay = detA * (A11 * RHS_y - A21_0 * RHS_x);
-    uveln = u_star + dt * ax;
-    vveln = v_star + dt * ay;
+    ax = detA * kid_fma(A22, RHS_x, -(A12_0 * RHS_y));
+    ay = detA * kid_fma(A11, RHS_y, -(A21_0 * RHS_x));
+    uveln = kid_fma(dt, ax, u_star);
+    vveln = kid_fma(dt, ay, v_star);
   }
   if (RK) { axn = 0.; ayn = 0.; }                                               // IB:2286
   else    { axn = ex + f_cori * vveln; ayn = ey - f_cori * uveln; }              // IB:2288-2297
   bxn = ax - (axn / 2); byn = ay - (ayn / 2);
   if (Sw<K>::speed_limit(p) > 0. || Sw<K>::speed_limit(p) == -1.) {  // IB:2304-2323: only the ticket counter survives
-    const double speed = sqrt(uveln * uveln + vveln * vveln);
+    const double speed = kid_sqrt(uveln * uveln + vveln * vveln);
     if (speed > 0.) {
       const int c = g.idx(i, j);
       const double loc_dx = dmin(0.5 * (g.dx[c] + g.dx[c - g.ni]), 0.5 * (g.dy[c] + g.dy[c - 1]));
@@ -737,6 +764,8 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
     if (OLD_ORDER) ap = accel_pre<K>(g, p, bg, cell.t0(3), cell.t0(4));
   }
   if (!OLD_ORDER) ap = accel_pre<K>(g, p, bg, stored.hi, stored.od);
+  // hot build: no lane of the wave in a cell with sea ice -> the ice velocity is not interpolated (interp_flds)
+  const bool need_ice = (FAST && OLD_ORDER && !(Sw<K>::coastal_drift(p) > 0.)) ? (__ballot(ap.c_ice != 0.) != 0ull) : true;
   double bxn = 0., byn = 0.;
   double x1 = 0., y1 = 0., xdot1 = 0., ydot1 = 0.;
   if (on_tang) { rotpos_to_tang(p, lon1, lat1, x1, y1); rotvec_to_tang(p, lon1, uvel1, vvel1, xdot1, ydot1); }
@@ -758,7 +787,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
     KID_PHASE_FENCE();
     double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
     KID_MARK("after_latterms");
-    if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e);
+    if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e, need_ice);
     if constexpr (!PRE_ONCE) ap = accel_pre<K>(g, p, bg, e.hi, e.od);
     KID_PHASE_FENCE();
     KID_MARK("after_interp");
@@ -879,7 +908,7 @@ __device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double 
   const double Dn = q * Tn;
   if (Dn > 0.) {
     if (!Sw<K>::use_updated_rolling_scheme(p) && Sw<K>::tip_parameter(p) < 999.) {          // scheme 3 (default)
-      if (dmax(Wn, Ln) < sqrt(0.92 * (Dn * Dn) + 58.32 * Dn)) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
+      if (dmax(Wn, Ln) < kid_sqrt(0.92 * (Dn * Dn) + 58.32 * Dn)) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
     } else {
       if (Wn > Ln) swapd(Ln, Wn);
       if (!Sw<K>::use_updated_rolling_scheme(p) && Sw<K>::tip_parameter(p) >= 999.) {       // scheme 2

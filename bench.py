@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""bench.py -- berg-steps/s of the MI355X evolve loop on BASELINE config 2 (configs[1]).
+"""bench.py -- berg-steps/s of the MI355X evolve loop at the size BASELINE.json's target names.
 
-Workload: 1e6 synthetic bergs (random mass classes) per GPU on the 360x200 lat-lon ocean grid, default namelist
-physics (RK4, drag + Coriolis + wave radiation + SSH slope, melt, rolling, rectangular mass spreading), fp64.
-One *step* is one icebergs_run() worth of the hot path over the whole population: device-side forcing prepass,
-accumulator zeroing, the fused per-berg kernel (evolve + thermodynamics + mass spreading), the cross-GPU sum of the
-per-cell accumulators (RCCL all-reduce, N>1 only) and the 9-point gather.  Inputs are resident in HBM before the
-timed region starts.  Weak scaling: every rank owns its own 1e6 bergs (different seeds), the grid is replicated.
+Workload: 1e7 synthetic bergs (random mass classes) per GPU -- the per-GPU share of BASELINE configs[4], with the physics
+of configs[1] -- on the 360x200 lat-lon ocean grid, default namelist (RK4, drag + Coriolis + wave radiation + SSH slope,
+melt, rolling, rectangular mass spreading), fp64.  One *step* is one icebergs_run() worth of the hot path over the whole
+population: device-side forcing prepass, accumulator zeroing, the fused per-berg kernel (evolve + thermodynamics + mass
+spreading), the cross-GPU sum of the per-cell accumulators (RCCL all-reduce, N>1 only) and the 9-point gather.  Inputs are
+resident in HBM before the timed region starts.  Weak scaling: every rank owns its own 1e7 bergs (different seeds), the
+grid is replicated.
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N>1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.
@@ -28,32 +29,72 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ALGO_BYTES_PER_BERG_STEP = 256.0  # SURVEY.md 8d (config 2): 129 B read + 128 B written of per-berg SoA state
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6           # MI355X vector fp64 peak
-# hot build, per berg-step: 637 FMA (x2) + 1066 ADD + ~1000 MUL fp64 lane-ops (SQ_INSTS_VALU_FMA_F64 / ADD_F64 x 64 lanes / 1e6 bergs)
-FP64_FLOP_PER_BERG_STEP = 3300.0
+N_SIMD, SIMD_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; one wave-instruction (64 lanes, fp64 included) issues per 4 cycles per SIMD
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc passes of this same command (tools/profiling/run_pmc.sh)
 
 
-def cpu_baseline(nbergs, nsteps):
-    """The CPU oracle (scalar C restatement of the reference loop), 1 core, on a bounded cut of the same workload."""
+def _cpu_worker(nbergs, nsteps, seed):
+    """one shard of the CPU baseline: the oracle (scalar C restatement of the reference loop) on `nbergs` bergs of config 2;
+    says READY when set up, starts on a line from stdin, prints its own wall time"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
     from icebergs_amd import synthetic as S
-    grid, p, b = S.config_c2(n=nbergs, seed=2)
+    grid, p, b = S.config_c2(n=nbergs, seed=seed)
     o = oracle_lib.Oracle(grid, p)
     o.run_step(b, 1)  # touch everything once
+    print("READY", flush=True)
+    sys.stdin.readline()
     t0 = time.perf_counter()
     o.run_step(b, nsteps)
-    dt = time.perf_counter() - t0
-    return {"value": nbergs * nsteps / dt, "unit": "berg-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d bergs x %d steps of config 2 (same generator, seed 2), oracle/kid_oracle.c -O2, 1 thread, %.1f s"
-                      % (nbergs, nsteps, dt)}
+    print(json.dumps({"seconds": time.perf_counter() - t0, "berg_steps": nbergs * nsteps}), flush=True)
+
+
+def _run_cpu_shards(nshards, nbergs, nsteps):
+    """`nshards` independent oracle processes (non-interacting bergs shard trivially) started together; wall time from the
+    common start to the last one finishing"""
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(nbergs), str(nsteps), str(2 + k)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for k in range(nshards)]
+    for q in procs:
+        line = q.stdout.readline()
+        if line.strip() != "READY":
+            raise RuntimeError("cpu baseline worker failed to start: %r" % line)
+    t0 = time.perf_counter()
+    for q in procs:
+        q.stdin.write("go\n"); q.stdin.flush()
+    outs = [json.loads(q.stdout.readline()) for q in procs]
+    wall = time.perf_counter() - t0
+    for q in procs:
+        q.wait()
+    return sum(o["berg_steps"] for o in outs), wall
+
+
+def cpu_baseline(nbergs, nsteps):
+    """The CPU oracle on the host cores of this node, on a bounded cut of the same workload: one core, then P independent
+    shards on P cores.  Runs in child processes that never touch the GPU, before this process initialises it."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    P = max(1, min(avail, int(os.environ.get("KID_CPU_BASELINE_CORES", "16"))))   # a 1-GPU box's CPU share is 16 cores
+    w1, t1 = _run_cpu_shards(1, nbergs, nsteps)
+    per = max(nbergs // 2, 1)
+    wP, tP = _run_cpu_shards(P, per, nsteps)
+    return {"value": wP / tP, "unit": "berg-steps/s", "cores": P, "kind": "port",
+            "one_core_value": w1 / t1,
+            "sample": "config 2 (same generator): 1 core: %d bergs x %d steps (%.1f s); %d cores: %d independent shards of %d bergs x %d steps, "
+                      "started together (%.1f s wall); oracle/kid_oracle.c -O2, one thread per shard; %d cores visible to this process"
+                      % (nbergs, nsteps, t1, P, P, per, nsteps, tP, avail)}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--bergs", type=int, default=1_000_000, help="bergs per GPU")
+    ap.add_argument("--bergs", type=int, default=10_000_000, help="bergs per GPU (BASELINE target: >= 1e7 bergs stepped; configs[4]: 1e7 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce and the gather on the critical path")
     ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
@@ -63,16 +104,19 @@ def main():
     ap.add_argument("--advance-clock", action="store_true", help="kid_set_params with an advancing current_yearday before every step, as a model run does")
     ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
-    ap.add_argument("--cpu-steps", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    # CPU baseline first, in GPU-free child processes, before this process touches the GPU (rank 0 at N=1 only)
+    cpu_line = cpu_baseline(args.cpu_bergs, args.cpu_steps) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
 
     import numpy as np
     import torch
     from icebergs_amd import synthetic as S, types as T
     from icebergs_amd.framework import Icebergs
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -151,10 +195,11 @@ def main():
     elapsed = time.perf_counter() - t0
     berg_ms, launches, _ = ib.profile_get()
     ib.profile(False)
+    elapsed_min = elapsed
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, elapsed_min = float(tt[0].item()), -float(tt[1].item())
     n_slots, n_alive = ib.num_bergs()
 
     if rank == 0:
@@ -165,39 +210,52 @@ def main():
         kern_ms = berg_ms / max(launches, 1)
         bergs_per_launch = args.bergs * args.steps / max(launches, 1)
         achieved = ALGO_BYTES_PER_BERG_STEP * bergs_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is
-        # the committed rocprofv3 --pmc measurement of this same command (profiles/r01_hbm_traffic.json), valid only
-        # for the population it was taken at
-        traffic, traffic_src = None, None
+        # HBM bytes and VALU instructions per launch of the dominant kernel: PMC counters cannot be read from inside the
+        # process, so these come from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_summary.json,
+        # tools/profiling/run_pmc.sh) and are reported only for the population those passes were taken at
+        traffic, traffic_src, valu_per_berg_step, pmc = None, None, None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-                tj = json.load(f)
-            if tj["bergs_per_launch"] == int(round(bergs_per_launch)):
-                traffic, traffic_src = tj["hbm_traffic_bytes_per_launch"], "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; gfx950 fetch correction x2)"
+            with open(PMC_SUMMARY) as f:
+                pmc = json.load(f)["hot"]
+            if abs(pmc["grid_size_mean"] - bergs_per_launch) <= 256:
+                traffic = pmc["hbm"]["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; gfx950 fetch correction x2)"
+                valu_per_berg_step = pmc["valu_wave_instr_per_berg_step"]
         except (OSError, KeyError, ValueError):
             pass
+        hbm_frac = achieved / HBM_PEAK_GBS
+        # the other bound: one wave-instruction (fp64 included) per 4 cycles per SIMD.  instructions per berg-step x waves / time
+        valu = None
+        if valu_per_berg_step and kern_ms > 0:
+            issue_s = valu_per_berg_step * (bergs_per_launch / 64.0) * 4.0 / (N_SIMD * SIMD_CLOCK_HZ)
+            valu = {"wave_instr_per_berg_step": valu_per_berg_step, "floor_ms": 1e3 * issue_s, "frac": issue_s / (kern_ms * 1e-3),
+                    "peak": "1 wave-instruction / 4 cycles / SIMD, %d SIMDs at %.1f GHz" % (N_SIMD, SIMD_CLOCK_HZ / 1e9),
+                    "source": "SQ_INSTS_VALU per launch / waves (profiles/r02_pmc_summary.json)"}
+        binding = "valu_fp64_issue" if (valu and valu["frac"] > hbm_frac) else "hbm"
         line = {
             "metric": "berg_steps_per_sec", "value": value, "unit": "berg-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
+            "config": {"workload": "BASELINE configs[4] per-GPU share with configs[1] physics: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
                                    "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s, ignore_traj=T" % args.bergs,
                        "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
-                       "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, ", overlapped with the next step's kernels" if pipelined else "")) if multi else "none (1 GPU)",
+                       "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) + %d scalars per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, T.NSCALAR, ", overlapped with the next step's kernels" if pipelined else "")) if multi else "none (1 GPU)",
+                       "planes_reduced_per_step": (nreduced // ib.ncell) if multi else 0, "MB_reduced_per_step": (nreduced * 8 / 1e6) if multi else 0.0,
                        "bergs_alive_at_end": n_alive},
             "per_gpu_value": value / world, "host_submit_ms_per_step": 1e3 * t_submit / args.steps,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "berg_kernel<true, true, 14u, true> (RK4, old interp order, evolve|thermo|spread, hot build)",
+            "ms_per_step_rank_max": 1e3 * elapsed / args.steps, "ms_per_step_rank_min": 1e3 * elapsed_min / args.steps,
+            # `bound` = the bound that binds the dominant kernel.  achieved / peak / frac are the HBM figures (algorithmic bytes over
+            # the kernel's launch time, the quantity BASELINE.json's target is stated in); `valu_fp64_issue` carries the other one.
+            "roofline": {"bound": binding, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                         "frac_of": "hbm", "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac},
+                         "valu_fp64_issue": valu,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "berg_kernel<true, true, 14u, true, 1> (RK4, old interp order, evolve|thermo|spread, hot build, plain namelist)",
                          "kernel_ms_avg": kern_ms, "kernel_launches": launches, "bergs_per_launch": bergs_per_launch,
-                         "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP,
-                         # SURVEY 8d asks for GFLOP/s beside GB/s: the kernel sits at the ridge (AI ~ 12 flop/B).  Flops per berg-step
-                         # from the committed PMC pass (profiles/r01_pmc_valu.txt: 2 x FMA_F64 + ADD_F64 + as many MUL_F64 as ADD, per lane)
-                         "fp64_flop_per_berg_step": FP64_FLOP_PER_BERG_STEP,
-                         "fp64_achieved_tflops": FP64_FLOP_PER_BERG_STEP * bergs_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
-                         "fp64_peak_tflops": FP64_PEAK_TFLOPS},
+                         "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_bergs, args.cpu_steps)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -27,12 +27,13 @@ def test_bench_line_contract():
     rf = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["bound"] in ("hbm", "valu_fp64_issue") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["frac_of"] == "hbm" and abs(rf["hbm"]["frac"] - rf["frac"]) < 1e-15
     assert rf["kernel_launches"] == 6 and rf["kernel_ms_avg"] > 0          # HIP events around every hot-build launch of the timed region
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["one_core_value"] > 0   # one core and all-core shards
 
 
 @pytest.mark.gpu

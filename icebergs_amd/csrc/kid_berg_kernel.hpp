@@ -54,7 +54,7 @@ template <int K> struct Fl {
 #define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
 #endif
 struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;    // k0, klen: the rows the hot build covers in this launch
-              int *fl_cursor; int32_t *fl_counter; long long fl_capacity; int fl_iNg; };   // PH_FL: where footloose children go (FlChildCtx)
+              int *fl_cursor; int32_t *fl_counter; long long fl_capacity; int fl_iNg; unsigned fl_step; };   // PH_FL: where footloose children go (FlChildCtx)
 // lane/step ("slow lane" schedule, launch_berg_lanes): lane[k] >= step means berg k is owned by general-build launches that
 // may still be running on the side stream; the hot build of this step leaves it alone.  A berg the hot build hands over
 // at step s gets lane = s + 1: the general build does its steps s and s + 1, the hot build has it back at s + 2.
@@ -240,7 +240,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     // The state goes through memory (this lane has just stored it); children are appended behind the population and get
     // their thermodynamics + spreading from a second launch over the new rows (kid_step_local).
     if (was_alive && !skipped && t.alive) {
-      const FlChildCtx cx{redo.fl_cursor, redo.fl_counter, n, redo.fl_capacity, redo.fl_iNg};
+      const FlChildCtx cx{redo.fl_cursor, redo.fl_counter, n, redo.fl_capacity, redo.fl_iNg, redo.fl_step};
       footloose_one(g, p, b, cx, kk, acc, ncell, scal);
       t.M = ldg(b.f[KID_B_MASS], kk); t.T = ldg(b.f[KID_B_THICKNESS], kk); t.W = ldg(b.f[KID_B_WIDTH], kk); t.L = ldg(b.f[KID_B_LENGTH], kk);
     }

@@ -1,15 +1,21 @@
 // kid_footloose.hpp -- footloose calving on the SoA (gfx950), one lane per berg.
-//   footloose_calving  IB:2503-2734      calve_fl_icebergs  IB:6405-6569      generate_id  FW:4165-4179
+//   footloose_calving  IB:2503-2734 (get_footloose_displacement IB:2688-2732)   calve_fl_icebergs  IB:6405-6569
+//   find_cell  FW:6011-6040      generate_id  FW:4165-4179
 // A calving event is rare (a parent sheds a child every few hundred steps), so this is a short streaming kernel
 // between the evolve and the thermodynamics launches.  New bergs are appended behind the population through an
 // atomic cursor; their ids come from the per-cell counter of the parent's cell (atomic, so ids are unique; when
 // two bergs of one cell calve in the same step the reference hands the counter values out in list order, here
-// the order is the atomics').  Only displace_fl_bergs=.false. exists: the displaced variant draws from FMS's
-// random stream.  The "new berg from FL bits" branch uses l_b of the berg at hand (the reference reuses the
-// local left by the previous berg of the loop, IB:2667).
+// the order is the atomics').  displace_fl_bergs: the child's place on the parent's perimeter comes from the counter-
+// based generator of include/kid_rng.h, keyed by (seed, parent id, footloose step, draw) -- the reference draws from
+// FMS's sequential stream in traversal order, which has no counterpart on a GPU; what follows the number (side and
+// offset, metres -> degrees, find_cell and its corner / grounded-cell fall-backs, pos_within_cell) is the reference's.
+// The "new berg from FL bits" branch uses l_b of the berg at hand (the reference reuses the local left by the
+// previous berg of the loop, IB:2667).
 #pragma once
 #include "kid_device.hpp"
 #include "kid_thermo.hpp"
+#define KID_RNG_FN __host__ __device__ static inline
+#include "../../include/kid_rng.h"
 
 namespace kid {
 
@@ -18,21 +24,93 @@ struct FlChildCtx {
   int32_t *counter;     // grd%iceberg_counter_grd
   long long n, capacity;
   int iNg;              // zonal size of the global grid (ij_component_of_id, FW:4227-4240)
+  unsigned step;        // the footloose step: third counter word of the random number generator (kid_rng.h)
 };
 
-// calve_fl_icebergs with displace=.false.; returns false if the SoA is full
+// find_cell FW:6011-6040: the structured-grid guess, then a scan of the computational domain (one lane; reached when the
+// guess fails, i.e. on grids that are not uniform in index space)
+__device__ __noinline__ bool fl_find_cell(const DevGrid &g, double x, double y, int &oi, int &oj) {
+  const GeoRec a = g.geo[g.idx(g.isd, g.jsd)], c = g.geo[g.idx(g.isd + 1, g.jsd + 1)];
+  oi = (int)floor((x - a.lon) / (c.lon - a.lon)) + g.isd + 1;
+  oj = (int)floor((y - a.lat) / (c.lat - a.lat)) + g.jsd + 1;
+  if (oi > g.isc - 1 && oi < g.iec + 1 && oj > g.jsc - 1 && oj < g.jec + 1)
+    if (is_point_in_cell<false>(g, GlbCell{g, g.idx(oi, oj)}.corners(), x, y)) return true;
+  oi = -999; oj = -999;
+  for (int j = g.jsc; j <= g.jec; ++j)
+    for (int i = g.isc; i <= g.iec; ++i)
+      if (is_point_in_cell<false>(g, GlbCell{g, g.idx(i, j)}.corners(), x, y)) { oi = i; oj = j; return true; }
+  return false;
+}
+
+// get_footloose_displacement IB:2688-2732
+__device__ __noinline__ void fl_displacement(const DevGrid &g, const kid_params &p, double rn, double lon, double lat, double length, double width,
+                                             double &fl_disp_x, double &fl_disp_y) {
+  double fx, fy, interp_loc;
+  if (rn < 0.25) { interp_loc = 4. * rn; fx = length * (interp_loc - 0.5); fy = 0.5 * width; }                 // north side
+  else if (rn < 0.5) { interp_loc = 4. * (rn - 0.25); fx = 0.5 * length; fy = width * (interp_loc - 0.5); }   // east side
+  else if (rn < 0.75) { interp_loc = 4. * (rn - 0.5); fx = length * (interp_loc - 0.5); fy = -0.5 * width; }  // south side
+  else { interp_loc = 4. * (rn - 0.75); fx = -0.5 * length; fy = 0.5 * width * (interp_loc - 0.5); }          // west side (the 0.5 is the reference's, IB:2714)
+  if (g.latlon) {
+    const bool on_tang = (lat > 89.);
+    double lon1 = lon, lat1 = lat, x1 = 0., y1 = 0.;
+    if (on_tang) rotpos_to_tang(p, lon1, lat1, x1, y1);
+    const double dxdl1 = (180. / p.pi) / (p.Rearth * cos(lat1 * (p.pi / 180.))), dydl = (180. / p.pi) / p.Rearth;   // IB:462-477
+    if (on_tang) {
+      double xdot2, ydot2;
+      rotvec_to_tang(p, lon1, fx, fy, xdot2, ydot2);
+      x1 = x1 + xdot2; y1 = y1 + ydot2;
+      rotpos_from_tang(p, x1, y1, lon1, lat1);
+    } else { lon1 = lon1 + fx * dxdl1; lat1 = lat1 + fy * dydl; }
+    fx = lon1 - lon; fy = lat1 - lat;
+  }
+  fl_disp_x = fx; fl_disp_y = fy;
+}
+
+// calve_fl_icebergs IB:6405-6569; `draw` picks the random number of this event; returns false if the SoA is full
 template <class BP>
-__device__ __forceinline__ bool calve_child(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long pk,
-                                            double k, double l_b, bool from_bits) {
+__device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long pk,
+                                         double k, double l_b, bool from_bits, unsigned draw) {
   const int slot = atomicAdd(cx.cursor, 1);
   const long long c = cx.n + slot;
   if (c >= cx.capacity) return false;
 #pragma unroll 1
   for (int f = 0; f < KID_NB_F64; ++f) b.f[f][c] = 0.0;
-  b.f[KID_B_LON][c] = b.f[KID_B_LON][pk]; b.f[KID_B_LAT][c] = b.f[KID_B_LAT][pk];
-  b.f[KID_B_XI][c] = b.f[KID_B_XI][pk]; b.f[KID_B_YJ][c] = b.f[KID_B_YJ][pk];
   const int pi = b.i[KID_BI_INE][pk], pj = b.i[KID_BI_JNE][pk];
-  b.i[KID_BI_INE][c] = pi; b.i[KID_BI_JNE][c] = pj;
+  const double plon = b.f[KID_B_LON][pk], plat = b.f[KID_B_LAT][pk];
+  double fl_disp_x = 0.0, fl_disp_y = 0.0;
+  bool displace = p.displace_fl_bergs != 0;
+  if (displace) {
+    // IB:2631 / 2664: a fresh number per event, or the one number of the run (fl_init_child_xy_by_pe)
+    const double rn = p.fl_init_child_xy_by_pe ? kid_fl_uniform((uint32_t)p.fl_rng_seed, 0, 0u, 0u)
+                                               : kid_fl_uniform((uint32_t)p.fl_rng_seed, b.id[pk], cx.step, draw);
+    const double plen = b.f[KID_B_LENGTH][pk], pwid = b.f[KID_B_WIDTH][pk];
+    fl_displacement(g, p, rn, plon, plat, plen, pwid, fl_disp_x, fl_disp_y);
+    double clon = plon + fl_disp_x, clat = plat + fl_disp_y;   // IB:6433-6435
+    int ci, cj;
+    bool lres = fl_find_cell(g, clon, clat, ci, cj);
+    if (!lres) {  // not in the computational domain: try the corners (IB:6438-6467; metres added to degrees as written)
+      clon = plon - 0.5 * plen; clat = plat - 0.5 * pwid; lres = fl_find_cell(g, clon, clat, ci, cj);
+      if (!lres) { clon = plon - 0.5 * plen; clat = plat + 0.5 * pwid; lres = fl_find_cell(g, clon, clat, ci, cj); }
+      if (!lres) { clon = plon + 0.5 * plen; clat = plat + 0.5 * pwid; lres = fl_find_cell(g, clon, clat, ci, cj); }
+      if (!lres) { clon = plon + 0.5 * plen; clat = plat - 0.5 * pwid; lres = fl_find_cell(g, clon, clat, ci, cj); }
+      if (!lres) { fl_disp_x = 0.0; fl_disp_y = 0.0; displace = false; }
+      else { fl_disp_x = plon - clon; fl_disp_y = plat - clat; }   // (sign as in the reference, IB:6466)
+    }
+    if (displace) {
+      if (g.geo[g.idx(ci, cj)].area == 0.) { fl_disp_x = 0.0; fl_disp_y = 0.0; displace = false; }   // grounded cell IB:6471-6472
+      else {
+        double xi, yj; int err = 0; bool bail = false;
+        (void)pos_within_cell<false>(g, p, GlbCell{g, g.idx(ci, cj)}, clon, clat, ci, cj, xi, yj, err, bail);
+        b.f[KID_B_LON][c] = clon; b.f[KID_B_LAT][c] = clat; b.f[KID_B_XI][c] = xi; b.f[KID_B_YJ][c] = yj;
+        b.i[KID_BI_INE][c] = ci; b.i[KID_BI_JNE][c] = cj;
+      }
+    }
+  }
+  if (!displace) {  // position = the parent's (IB:6479-6486)
+    b.f[KID_B_LON][c] = plon; b.f[KID_B_LAT][c] = plat;
+    b.f[KID_B_XI][c] = b.f[KID_B_XI][pk]; b.f[KID_B_YJ][c] = b.f[KID_B_YJ][pk];
+    b.i[KID_BI_INE][c] = pi; b.i[KID_BI_JNE][c] = pj;
+  }
   const double pms = b.f[KID_B_MASS_SCALING][pk];
   if (from_bits) {  // IB:6488-6497
     double Lfl, Wfl, Tfl;
@@ -53,7 +131,7 @@ __device__ __forceinline__ bool calve_child(const DevGrid &g, const kid_params &
     b.f[KID_B_MASS_OF_BITS][c] = 0.0;
   }
   b.f[KID_B_START_LON][c] = b.f[KID_B_LON][c]; b.f[KID_B_START_LAT][c] = b.f[KID_B_LAT][c];
-  b.f[KID_B_LON_OLD][c] = b.f[KID_B_LON_OLD][pk] + 0.0; b.f[KID_B_LAT_OLD][c] = b.f[KID_B_LAT_OLD][pk] + 0.0;
+  b.f[KID_B_LON_OLD][c] = b.f[KID_B_LON_OLD][pk] + fl_disp_x; b.f[KID_B_LAT_OLD][c] = b.f[KID_B_LAT_OLD][pk] + fl_disp_y;
   b.f[KID_B_START_DAY][c] = p.current_yearday;
   b.f[KID_B_MASS_OF_FL_BITS][c] = 0.0; b.f[KID_B_MASS_OF_FL_BERGY_BITS][c] = 0.0;
   b.f[KID_B_FL_K][c] = -1.0;
@@ -117,7 +195,7 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
       }
       const double dA = L * W - Ln * Wn;
       if (p.fl_style == KID_FL_STYLE_NEW_BERGS) {
-        if (!calve_child(g, p, b, cx, q, k, l_b, false)) nerr += 1.;
+        if (!calve_child(g, p, b, cx, q, k, l_b, false, 0u)) nerr += 1.;
         ncalved += 1.;
       } else {
         const double dM_fl_bits = p.rho_bergs * T * dA;
@@ -135,7 +213,7 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
   const double bits = b.f[KID_B_MASS_OF_FL_BITS][q];
   if (bits * ms > p.new_berg_from_fl_bits_mass_thres) {  // IB:2663-2673
     const double k = floor(bits * ms / p.new_berg_from_fl_bits_mass_thres);
-    if (!calve_child(g, p, b, cx, q, k, l_b, true)) nerr += 1.;
+    if (!calve_child(g, p, b, cx, q, k, l_b, true, 1u)) nerr += 1.;
     ncalved += 1.;
     if (area != 0.) unsafeAtomicAdd(acc + (size_t)KID_A_FL_BITS_SRC * ncell + c, -(k * p.new_berg_from_fl_bits_mass_thres / (p.dt * area)));
   }

@@ -339,6 +339,7 @@ struct kid_handle {
   hipEvent_t evC = nullptr, evP = nullptr;
   VelRec *d_vel2 = nullptr; TrcRec *d_trc2 = nullptr; DevGrid *d_grid2 = nullptr; int forc_parity = 0;  // forcing records of the odd steps
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
+  unsigned fl_step = 0;                  // footloose passes so far: third counter word of the child-placement generator (kid_rng.h)
   int *d_fl_cursor = nullptr;
   unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
   void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
@@ -437,7 +438,6 @@ static int check_params(kid_handle *h, const kid_params *p) {
     h->err = "find_melt_using_spread_mass is implemented for the plain evolve loop only (no bonds, interactions or footloose)";
     return KID_EUNSUPPORTED;
   }
-  if (p->footloose && p->displace_fl_bergs) { h->err = "footloose with displace_fl_bergs needs FMS's random stream: use displace_fl_bergs=F"; return KID_EUNSUPPORTED; }
   if (p->Runge_not_Verlet && p->footloose) { h->err = "Runge_not_Verlet must be false to use footloose (FW:1485-1490)"; return KID_EINVAL; }
   if (p->footloose && !p->use_operator_splitting) { h->err = "use_operator_splitting must be true to use footloose (FW:1476)"; return KID_EINVAL; }
   return KID_OK;
@@ -1084,7 +1084,7 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
     const long long klen = (nparts == 1) ? (range_len < 0 ? h->n : range_len) : (part == 0 ? half : h->n - half);
     const unsigned nbp = (unsigned)((klen + 255) / 256);
     const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen, nullptr, 0,
-                    h->d_fl_cursor, h->d_iceberg_counter, (long long)h->capacity, h->gd.iec - h->gd.isc + 1};
+                    h->d_fl_cursor, h->d_iceberg_counter, (long long)h->capacity, h->gd.iec - h->gd.isc + 1, h->fl_step};
     hipStream_t gs = (nparts == 2) ? h->side_stream : h->stream;
     if (h->evG_live[part]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[part], 0));
     if (nparts == 1 && h->evG_live[1]) KID_HIP(h, hipStreamWaitEvent(h->stream, h->evG[1], 0));
@@ -1248,7 +1248,7 @@ int kid_footloose_calving(kid_handle *h) {
   if (rc) return rc;
   h->flags.has_fl = 1;
   KID_HIP(h, hipMemsetAsync(h->d_fl_cursor, 0, sizeof(int), h->stream));
-  FlChildCtx cx{h->d_fl_cursor, h->d_iceberg_counter, (long long)h->n, (long long)h->capacity, h->gd.iec - h->gd.isc + 1};
+  FlChildCtx cx{h->d_fl_cursor, h->d_iceberg_counter, (long long)h->n, (long long)h->capacity, h->gd.iec - h->gd.isc + 1, h->fl_step++};
   hipLaunchKernelGGL(footloose_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), h->d_params, h->d_bp, cx, h->d_acc, h->ncell);
   KID_HIP(h, hipGetLastError());
   int appended = 0;  // the population grew: the host needs the new size before the next launch
@@ -1261,6 +1261,19 @@ int kid_footloose_calving(kid_handle *h) {
     return KID_ECAPACITY;
   }
   h->n += appended;
+  return KID_OK;
+}
+double kid_footloose_uniform(int32_t seed, int64_t berg_id, int64_t step, int32_t draw) {   // the number a child placement uses (host side of kid_rng.h)
+  return kid_fl_uniform((uint32_t)seed, berg_id, (uint32_t)step, (uint32_t)draw);
+}
+int kid_set_footloose_step(kid_handle *h, int64_t step) {   // restart: continue the child-placement sequence (kid_rng.h)
+  if (!h || step < 0) return KID_EINVAL;
+  h->fl_step = (unsigned)step;
+  return KID_OK;
+}
+int kid_get_footloose_step(kid_handle *h, int64_t *step) {
+  if (!h || !step) return KID_EINVAL;
+  *step = (int64_t)h->fl_step;
   return KID_OK;
 }
 int kid_set_iceberg_counter(kid_handle *h, const int32_t *counter) {  // grd%iceberg_counter_grd, (isd:ied,jsd:jed)
@@ -1335,6 +1348,7 @@ int kid_step_local(kid_handle *h) {
     KID_HIP(h, hipMemsetAsync(h->d_fl_cursor, 0, sizeof(int), h->stream));
     const long long n_old = h->n;
     rc = p.old_interp_flds_order ? launch_berg<PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD>(h);
+    h->fl_step += 1u;   // one footloose pass (hot and general build of this launch share the step word)
     if (rc) return rc;
     int appended = 0;  // the population grew: the host needs the new size before the next launch
     KID_HIP(h, hipMemcpyAsync(&appended, h->d_fl_cursor, sizeof(int), hipMemcpyDeviceToHost, h->stream));

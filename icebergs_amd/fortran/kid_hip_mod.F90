@@ -26,6 +26,7 @@ module kid_hip_mod
   public :: kid_buffer_width, kid_pack_emigrants, kid_unpack_immigrants, kid_pack_emigrants_pair, kid_unpack_immigrants_pair, KID_DIR_E, KID_DIR_W, KID_DIR_N, KID_DIR_S
   public :: kid_traj_params, kid_set_traj_params, kid_record_posn, kid_write_trajectories, kid_write_bond_trajectories
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
+  public :: kid_set_footloose_step, kid_get_footloose_step
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
   public :: KID_NGRID_STATIC, KID_NFORCING, KID_NB_F64, KID_NB_I32, KID_NACC, KID_NOUT, KID_NSCALAR
@@ -208,6 +209,16 @@ module kid_hip_mod
     integer(c_int) function kid_footloose_calving(h) bind(C, name='kid_footloose_calving')          ! IB:5453
       import :: c_int, c_ptr
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_set_footloose_step(h, step) bind(C, name='kid_set_footloose_step')  ! child-placement sequence (kid_rng.h)
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), value :: step
+    end function
+    integer(c_int) function kid_get_footloose_step(h, step) bind(C, name='kid_get_footloose_step')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: step
     end function
     integer(c_int) function kid_step_prepare(h, fields) bind(C, name='kid_step_prepare')
       import :: c_int, c_ptr

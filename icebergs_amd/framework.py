@@ -336,6 +336,15 @@ class Icebergs:
     def set_store_environment(self, on):
         self._check(self.lib.kid_set_store_environment(self.h, 1 if on else 0), "kid_set_store_environment")
 
+    def set_footloose_step(self, step):
+        """continue the child-placement sequence of a restarted run (include/kid_rng.h)"""
+        self._check(self.lib.kid_set_footloose_step(self.h, int(step)), "kid_set_footloose_step")
+
+    def get_footloose_step(self):
+        s = C.c_int64(0)
+        self._check(self.lib.kid_get_footloose_step(self.h, C.byref(s)), "kid_get_footloose_step")
+        return int(s.value)
+
     def set_iceberg_counter(self, counter):
         a = np.ascontiguousarray(counter, dtype=np.int32)
         assert a.shape == (self.nj, self.ni)

@@ -16,7 +16,7 @@ SYMBOLS = [
     "kid_create", "kid_destroy", "kid_set_params", "kid_set_stream", "kid_sync", "kid_last_error", "kid_version",
     "kid_sizeof", "kid_set_static_grid", "kid_set_forcing", "kid_set_forcing_device", "kid_upload_bergs", "kid_download_bergs",
     "kid_num_bergs", "kid_compact_bergs", "kid_move_berg_between_cells", "kid_set_resort_interval", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
-    "kid_evolve_icebergs", "kid_footloose_calving", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
+    "kid_evolve_icebergs", "kid_footloose_calving", "kid_set_footloose_step", "kid_get_footloose_step", "kid_footloose_uniform", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
     "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
     "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
@@ -111,6 +111,9 @@ def load():
         getattr(lib, name).argtypes = [H]
     lib.kid_run_step.argtypes = [H, C.c_int]
     lib.kid_set_store_environment.argtypes = [H, C.c_int]
+    lib.kid_footloose_uniform.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.c_int32]
+    lib.kid_set_footloose_step.argtypes = [H, C.c_int64]
+    lib.kid_get_footloose_step.argtypes = [H, C.POINTER(C.c_int64)]
     lib.kid_set_iceberg_counter.argtypes = [H, C.POINTER(C.c_int32)]
     lib.kid_get_iceberg_counter.argtypes = [H, C.POINTER(C.c_int32)]
     lib.kid_get_accumulators.argtypes = [H, dp, dp, dp]
@@ -119,8 +122,9 @@ def load():
     lib.kid_profile_enable.argtypes = [H, C.c_int]
     lib.kid_profile_get.argtypes = [H, dp, C.POINTER(C.c_int64), dp]
     for name in SYMBOLS:
-        if name not in ("kid_version", "kid_last_error", "kid_sizeof"):
+        if name not in ("kid_version", "kid_last_error", "kid_sizeof", "kid_footloose_uniform"):
             getattr(lib, name).restype = C.c_int
+    lib.kid_footloose_uniform.restype = C.c_double
     assert lib.kid_sizeof(0) == C.sizeof(T.Params), "kid_params layout mismatch between header and library"
     assert lib.kid_sizeof(1) == C.sizeof(T.GridDesc)
     assert lib.kid_sizeof(2) == C.sizeof(T.BergSoA)

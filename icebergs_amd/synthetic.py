@@ -315,12 +315,15 @@ def config_c2(n=1_000_000, seed=2, continents=False):
     return grid, p, b
 
 
-def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3, dt=600.0, spread=False):
+def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3, dt=600.0, spread=False, displace=False, periodic=False,
+              by_pe=False):
     """BASELINE config 3, the footloose profile of tests/footloose_tests/input.nml: Cartesian 1 km grid, Verlet,
     footloose calving into FL bits (or child bergs), 300 m thick tabular bergs with +-20 % jitter, ocean 1 m/s east,
     wind stress -1 (about -25.8 m/s as a wind), SST -0.5.  The arrays carry spare rows for children (b["_n"] live).
-    fl_k starts at a random fraction of a foot so that calving starts within tens of steps."""
-    grid = cartesian_grid(ni, nj, 1000.0, Lx=-1.0)
+    fl_k starts at a random fraction of a foot so that calving starts within tens of steps.
+    displace: displace_fl_bergs=T as in the profile's own namelist (children placed on the parent's perimeter with the
+    counter-based generator, include/kid_rng.h); periodic: the channel is zonally periodic (Lx = ni km) as in the profile."""
+    grid = cartesian_grid(ni, nj, 1000.0, Lx=(ni * 1000.0 if periodic else -1.0))
     F = grid["forcing"]
     F["uo"][:] = 1.0
     jmid = F["vo"].shape[0] // 2
@@ -332,7 +335,9 @@ def config_c3(n=100, seed=3, ni=64, nj=20, fl_style="fl_bits", capacity_factor=3
     p = default_params()
     p.dt, p.lat_ref, p.use_f_plane = dt, -70.0, 1
     p.Runge_not_Verlet = 0
-    p.footloose, p.displace_fl_bergs = 1, 0
+    p.footloose, p.displace_fl_bergs = 1, (1 if displace else 0)
+    p.fl_init_child_xy_by_pe, p.fl_rng_seed = (1 if by_pe else 0), 20240807
+    p.periodic_reentry = 1 if periodic else 0
     p.fl_style = T.ENUMS["KID_FL_STYLE_FL_BITS" if fl_style == "fl_bits" else "KID_FL_STYLE_NEW_BERGS"]
     p.fl_youngs, p.fl_strength = 1.0e8, 250.0
     p.new_berg_from_fl_bits_mass_thres = 3.0e11

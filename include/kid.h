@@ -195,6 +195,13 @@ int kid_zero_accumulators(kid_handle *h);
 int kid_interp_gridded_fields_to_bergs(kid_handle *h);
 int kid_evolve_icebergs(kid_handle *h);
 int kid_footloose_calving(kid_handle *h);
+/* Footloose children are placed on their parent's perimeter (displace_fl_bergs, IB:2631, 2664, 6432-6498) with the
+ * counter-based generator of include/kid_rng.h: rn = f(kid_params.fl_rng_seed, parent id, footloose step, draw).  The step
+ * counts the footloose passes of this handle (0 at kid_create, +1 per kid_footloose_calving or fused footloose step);
+ * a restarted run sets it to continue the sequence.  (The reference seeds FMS's stream from the PE and the time, IB:2548.) */
+double kid_footloose_uniform(int32_t seed, int64_t berg_id, int64_t step, int32_t draw);   /* the generator, for hosts that want to check a placement */
+int kid_set_footloose_step(kid_handle *h, int64_t step);
+int kid_get_footloose_step(kid_handle *h, int64_t *step);
 int kid_thermodynamics(kid_handle *h);
 int kid_create_gridded_icebergs_fields(kid_handle *h);
 

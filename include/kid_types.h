@@ -348,6 +348,9 @@ typedef struct kid_params {
                                            unpack_berg_from_buffer2 FW:3573-3577, 3628-3635), and the 9-point gather reads across the
                                            seam (mpp_update_domains in sum_up_spread_fields, IB:6103).  0: the berg is removed, as
                                            on a PE without that neighbour */
+  int32_t fl_init_child_xy_by_pe;       /* FW:606, 816: one random number for the whole run (old bug) instead of one per calving event */
+  int32_t fl_rng_seed;                  /* seed of the counter-based generator that places footloose children (include/kid_rng.h); the
+                                           reference seeds FMS's stream from (mpp_pe(), time), IB:2548 */
   int32_t pad1;                         /* explicit: no implicit tail padding (Fortran stream I/O moves components) */
 } kid_params;
 

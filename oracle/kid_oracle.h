@@ -67,6 +67,15 @@ void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double
 void ko_step_local(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity, double *acc, double *scalars);
 void ko_footloose_calving(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
                           double *acc, double *scalars);
+void ko_meters_to_grid(const ko_grid *g, const kid_params *p, double lat_ref, double *dlon_dx, double *dlat_dy);
+void ko_rotpos_to_tang(const kid_params *p, double lon, double lat, double *x, double *y);
+void ko_rotpos_from_tang(const kid_params *p, double x, double y, double *lon, double *lat);
+void ko_rotvec_to_tang(const kid_params *p, double lon, double uvel, double vvel, double *xdot, double *ydot);
+void ko_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double ko_fl_uniform(int32_t seed, int64_t berg_id, int64_t step, int32_t draw);
+/* the footloose step (number of footloose_calving calls so far): third counter word of the generator in include/kid_rng.h */
+void ko_set_fl_step(int64_t step);
+int64_t ko_get_fl_step(void);
 /* One icebergs_run() worth of the hot path (IB:5423-5512), accumulators zeroed first.
  * acc: KID_NACC fields of (ied-isd+1)*(jed-jsd+1); out: KID_NOUT fields; scalars: KID_NSCALAR. */
 void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,

@@ -82,6 +82,11 @@ def load():
     lib.ko_thermodynamics.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
     lib.ko_create_gridded_icebergs_fields.restype = None
     lib.ko_create_gridded_icebergs_fields.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
+    lib.ko_philox4x32_10.restype = None
+    lib.ko_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.ko_fl_uniform.restype = d; lib.ko_fl_uniform.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.c_int32]
+    lib.ko_set_fl_step.restype = None; lib.ko_set_fl_step.argtypes = [C.c_int64]
+    lib.ko_get_fl_step.restype = C.c_int64; lib.ko_get_fl_step.argtypes = []
     lib.ko_footloose_calving.restype = None
     lib.ko_footloose_calving.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.c_int64, C.POINTER(d), C.POINTER(d)]
     lib.ko_step_local.restype = None
@@ -255,16 +260,23 @@ class Oracle:
 
     def step_local(self, bergs):
         s = self.soa(bergs)
+        self.lib.ko_set_fl_step(getattr(self, "fl_step", 0))
+        self._after_fl = True
         self.lib.ko_step_local(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]), _dp(self.acc), _dp(self.scalars))
+        self.fl_step = int(self.lib.ko_get_fl_step())
 
     def step_gather(self):
         self.lib.ko_gather_fields(C.byref(self.kg), C.byref(self.params), _dp(self.acc), _dp(self.out))
 
     def run_step(self, bergs, nsteps=1):
         s = self.soa(bergs)
+        # the footloose step (third counter word of the child-placement generator) is kept per Oracle object: the C library
+        # holds one global
+        self.lib.ko_set_fl_step(getattr(self, "fl_step", 0))
         for _ in range(nsteps):
             self.lib.ko_run_step(C.byref(self.kg), C.byref(self.params), C.byref(s), len(bergs["lon"]),
                                  _dp(self.acc), _dp(self.out), _dp(self.scalars))
+        self.fl_step = int(self.lib.ko_get_fl_step())
         if "_n" in bergs:
             bergs["_n"] = int(s.n)  # footloose calving appends children
         return bergs

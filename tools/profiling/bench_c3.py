@@ -8,7 +8,7 @@ from icebergs_amd.framework import Icebergs
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 t0 = time.time()
-grid, p, b = S.config_c3(n=n, seed=3, ni=2000, nj=1000, fl_style="fl_bits", capacity_factor=1.3, dt=10.0, spread=True)
+grid, p, b = S.config_c3(n=n, seed=3, ni=2000, nj=1000, fl_style="fl_bits", capacity_factor=1.3, dt=10.0, spread=True, displace=True, periodic=True)   # the profile's own namelist: displaced children, periodic channel
 print("generated %d bergs in %.1f s" % (n, time.time() - t0), flush=True)
 cap = len(b["lon"])
 ib = Icebergs(grid, p, capacity=cap, device=0)

@@ -1505,3 +1505,4 @@ int kid_profile_get(kid_handle *h, double *berg_ms, int64_t *launches, double *a
 #include "kid_restart.inc"
 #include "kid_traj.inc"
 #include "kid_migrate.inc"
+#include "kid_chksum.inc"

@@ -22,7 +22,7 @@ module kid_hip_mod
   public :: kid_forcing_in, kid_ingest_forcing, kid_get_forcing, KID_BGRID_NE, KID_CGRID_NE, KID_AGRID
   public :: kid_calving_params, kid_calving_in, kid_set_calving_params, kid_set_calving_state, kid_get_calving_state
   public :: kid_calving, kid_get_calving, KID_NCALV_SCALARS, KID_NCLASSES
-  public :: kid_write_restart, kid_read_restart
+  public :: kid_write_restart, kid_read_restart, kid_bergs_chksum
   public :: kid_buffer_width, kid_pack_emigrants, kid_unpack_immigrants, kid_pack_emigrants_pair, kid_unpack_immigrants_pair, KID_DIR_E, KID_DIR_W, KID_DIR_N, KID_DIR_S
   public :: kid_traj_params, kid_set_traj_params, kid_record_posn, kid_write_trajectories, kid_write_bond_trajectories
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
@@ -116,6 +116,11 @@ module kid_hip_mod
       import :: c_int, c_ptr, c_char
       type(c_ptr), value :: h
       character(kind=c_char), intent(in) :: dir(*)
+    end function
+    integer(c_int) function kid_bergs_chksum(h, chk) bind(C, name='kid_bergs_chksum')   ! bergs_chksum FW:6889: chksum..chksum5, #
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: chk(6)
     end function
     integer(c_int) function kid_read_restart(h, dir) bind(C, name='kid_read_restart')
       import :: c_int, c_ptr, c_char

@@ -336,6 +336,12 @@ class Icebergs:
     def set_store_environment(self, on):
         self._check(self.lib.kid_set_store_environment(self.h, 1 if on else 0), "kid_set_store_environment")
 
+    def bergs_chksum(self):
+        """(chksum, chksum2, chksum3, chksum4, chksum5, #) of bergs_chksum (FW:6889-6987), as the reference prints them"""
+        out = (C.c_int64 * 6)()
+        self._check(self.lib.kid_bergs_chksum(self.h, out), "kid_bergs_chksum")
+        return tuple(int(v) for v in out)
+
     def set_footloose_step(self, step):
         """continue the child-placement sequence of a restarted run (include/kid_rng.h)"""
         self._check(self.lib.kid_set_footloose_step(self.h, int(step)), "kid_set_footloose_step")

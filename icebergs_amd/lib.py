@@ -22,7 +22,7 @@ SYMBOLS = [
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
     "kid_ingest_forcing", "kid_get_forcing",
     "kid_set_calving_params", "kid_set_calving_state", "kid_get_calving_state", "kid_calving", "kid_get_calving",
-    "kid_restart_write_bergs", "kid_restart_count_bergs", "kid_restart_read_bergs", "kid_restart_write_bonds", "kid_restart_read_bonds", "kid_write_restart", "kid_read_restart",
+    "kid_restart_write_bergs", "kid_restart_count_bergs", "kid_restart_read_bergs", "kid_restart_write_bonds", "kid_restart_read_bonds", "kid_write_restart", "kid_read_restart", "kid_bergs_chksum",
     "kid_set_traj_params", "kid_record_posn", "kid_num_traj_records", "kid_write_trajectories",
     "kid_num_bond_traj_records", "kid_write_bond_trajectories",
     "kid_buffer_width", "kid_pack_emigrants", "kid_unpack_immigrants", "kid_pack_emigrants_pair", "kid_unpack_immigrants_pair",
@@ -111,6 +111,7 @@ def load():
         getattr(lib, name).argtypes = [H]
     lib.kid_run_step.argtypes = [H, C.c_int]
     lib.kid_set_store_environment.argtypes = [H, C.c_int]
+    lib.kid_bergs_chksum.argtypes = [H, C.POINTER(C.c_int64)]
     lib.kid_footloose_uniform.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.c_int32]
     lib.kid_set_footloose_step.argtypes = [H, C.c_int64]
     lib.kid_get_footloose_step.argtypes = [H, C.POINTER(C.c_int64)]

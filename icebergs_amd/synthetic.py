@@ -416,9 +416,33 @@ def bond_neighbours(b, n, reach, max_bonds=6):
     return bd
 
 
+def dem_ground_frac_elements(radius=1.5e3, xc=50000.0, yc=50000.0, xl=15000.0, yl=35000.0):
+    """Element centres of the reference's tests/dem_ground_frac_test: its generator's parameters (makeberg/makeberg.py:241-257:
+    one conglomerate, a 15 km x 35 km rectangle centred on (50 km, 50 km), element radius 1.5 km) and its hexagonal packing
+    loop (:284-325: columns sqrt(3) r apart starting 2r/sqrt(3) inside the western edge, every other column shifted north by r,
+    elements 2r apart from r inside the southern edge up to the northern edge) restated -- 69 elements, the '#=69' of the
+    regression line recorded in that test's namelist (input.nml:7, 10)."""
+    xmin, xmax, ymin, ymax = xc - 0.5 * xl, xc + 0.5 * xl, yc - 0.5 * yl, yc + 0.5 * yl
+    xs, ys = [], []
+    x_start, y_start0 = min(xmin + radius * 2.0 / np.sqrt(3.0), xmax), min(ymin + radius, ymax)
+    j, x_val = 0, x_start
+    while xmin <= x_val <= xmax:
+        y_start = y_start0 + (j % 2) * radius
+        k, y_val = 0, y_start
+        while y_val <= ymax:
+            xs.append(x_val)
+            ys.append(y_val)
+            k += 1
+            y_val = y_start + 2 * k * radius
+        j += 1
+        x_val = x_start + np.sqrt(3.0) * radius * j
+    return xs, ys
+
+
 def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45, nj=45, gridres=5000.0, sub_steps=200,
               bump=(58.0e3, 60.0e3), bump_depth=50.0, origin=(44137.0, 35211.0), frac=(1850.0, 1000.0), thickness_jitter=0.0,
-              seed=4, two_bergs=False, dem=True, explicit_inner=True, spring_coef=None, dt=1800.0, mts=True, contact=True):
+              seed=4, two_bergs=False, dem=True, explicit_inner=True, spring_coef=None, dt=1800.0, mts=True, contact=True,
+              reference_pattern=False):
     """BASELINE config 4 family: a tabular berg made of bonded DEM elements (hexagonal or square packing) drifting at
     0.1 m/s onto a Gaussian seamount on the Cartesian grid of tests/dem_ground_frac_test (driver DRV:288-307,
     namelist tests/dem_ground_frac_test/input.nml): MTS velocity Verlet with explicit DEM sub-steps, stress fracture
@@ -429,6 +453,8 @@ def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45
     d = grid["desc"]
     ii, jj = _ij(d)
     xc, yc = gridres * ii - gridres / 2.0, gridres * jj - gridres / 2.0
+    if reference_pattern:
+        bump = (63.0e3, 60.0e3)   # the driver's own seamount for this test (DRV:299), 5.5 km east of the conglomerate's edge
     a, cw = 1000.0 - bump_depth, 5.0e3
     grid["static"]["ocean_depth"][:] = 1000.0 - a * np.exp(-((xc - bump[0]) ** 2 / (2 * cw * cw) + (yc - bump[1]) ** 2 / (2 * cw * cw)))
     F = grid["forcing"]
@@ -459,7 +485,12 @@ def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45
     p.apply_thickness_cutoff_to_gridded_melt, p.apply_thickness_cutoff_to_bergs_melt, p.melt_cutoff = 1, 1, 10.0
     # elements
     xs, ys = [], []
-    if hexagonal:
+    if reference_pattern:   # the element pattern of tests/dem_ground_frac_test itself (69 elements); melt off as in its namelist (:128)
+        p.set_melt_rates_to_zero = 1
+        xs, ys = dem_ground_frac_elements(radius)
+        area = (3.0 * np.sqrt(3.0) / 2.0) * ((4.0 / 3.0) * radius ** 2)
+        nx, ny = len(xs), 1
+    elif hexagonal:
         for jcol in range(nx):
             for krow in range(ny):
                 xs.append(origin[0] + radius * 2.0 / np.sqrt(3.0) + np.sqrt(3.0) * radius * jcol)

@@ -151,6 +151,12 @@ int kid_restart_read_bonds(const char *path, const kid_berg_soa *bergs, kid_bond
  * recomputed on the device from (lon, lat, ine, jne) (IO2:945) */
 int kid_write_restart(kid_handle *h, const char *dir);
 int kid_read_restart(kid_handle *h, const char *dir);
+/* bergs_chksum (FW:6889-6987: the "write_restart berg chksum=.. chksum2=.. chksum3=.. chksum4=.. chksum5=.. #=.." line of
+ * icebergs_save_restart, IB:8145, which the reference's regression tests record) on the resident population:
+ * out[0..4] = chksum, chksum2, chksum3, chksum4, chksum5 as the default integers the reference prints, out[5] = #, the number
+ * of bergs on the computational domain.  FMS's mpp_chksum is restated (wrap-around sum of bit patterns); see
+ * csrc/kid_chksum.inc for the quirks that are reproduced on purpose. */
+int kid_bergs_chksum(kid_handle *h, int64_t out[6]);
 
 /* ---- trajectories: record_posn (FW:5328-5498) as a device pass that appends one record per selected berg
  * to buffers in HBM, and iceberg_trajectories.nc (icebergs_fms2io.F90:1631-2103) written from them: dimension "i", lon,

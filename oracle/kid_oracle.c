@@ -1668,3 +1668,80 @@ long ko_unpack_bergs(const ko_grid *g, const kid_params *p, kid_berg_soa *b, con
   }
   return lost;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * bergs_chksum FW:6889-6987, berg_chksum FW:6990-7068, time_hash / pos_hash FW:4364-4376; mpp_chksum (FMS, not in the
+ * reference tree): wrap-around 64-bit sum of the IEEE bit patterns, kept as a default integer (low 32 bits).
+ * Followed to the letter: i and chksum5 start over in every cell (FW:6919); transfer(rtmp,i8) has a scalar mold, so
+ * itmp(1:36) are 36 copies of the low word of rtmp(1) = lon (FW:7055).  b must be in reference traversal order
+ * (ko_reference_order).  out = chksum, chksum2, chksum3, chksum4, chksum5, # of bergs on the computational domain.
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t dbits(double x) { uint64_t u; memcpy(&u, &x, sizeof(u)); return u; }
+static int32_t one_berg_chksum(const kid_berg_soa *b, int64_t k) {
+  uint32_t itmp[43];
+  const uint32_t w = (uint32_t)dbits(b->f64[KID_B_LON][k]);
+  for (int q = 0; q < 36; ++q) itmp[q] = w;
+  itmp[36] = (uint32_t)(int32_t)(b->f64[KID_B_HALO_BERG] ? b->f64[KID_B_HALO_BERG][k] : 0.);
+  itmp[37] = (uint32_t)(int32_t)(b->f64[KID_B_STATIC_BERG] ? b->f64[KID_B_STATIC_BERG][k] : 0.);
+  itmp[38] = (uint32_t)(b->i32[KID_BI_START_YEAR] ? b->i32[KID_BI_START_YEAR][k] : 0);
+  itmp[39] = (uint32_t)b->i32[KID_BI_INE][k]; itmp[40] = (uint32_t)b->i32[KID_BI_JNE][k];
+  const int64_t id = b->id ? b->id[k] : 0;
+  itmp[41] = (uint32_t)(int32_t)(id >> 32); itmp[42] = (uint32_t)(int32_t)(id & 0xFFFFFFFFll);
+  uint32_t c1 = 0, c2 = 0, c3 = 0;
+  for (uint32_t q = 1; q <= 43; ++q) { c1 += itmp[q - 1]; c2 += itmp[q - 1] * q; c3 += itmp[q - 1] * q * q; }
+  return (int32_t)(c1 + c2 + c3);
+}
+void ko_bergs_chksum(const ko_grid *g, const kid_berg_soa *b, int64_t out[6]) {
+  const kid_grid_desc *d = &g->d;
+  const size_t ncell = (size_t)NI(g) * (size_t)(d->jed - d->jsd + 1);
+  int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)(b->n > 0 ? b->n : 1));
+  ko_reference_order(b, perm);
+  int64_t nb = 0;
+  for (int64_t q = 0; q < b->n; ++q) {
+    const int64_t k = perm[q];
+    const int i = b->i32[KID_BI_INE][k], j = b->i32[KID_BI_JNE][k];
+    if (berg_alive(b, k) && i >= d->isc && i <= d->iec && j >= d->jsc && j <= d->jec) nb += 1;
+  }
+  const int64_t rows = nb > 0 ? nb : 1;
+  double *fld = (double *)calloc((size_t)rows * 19, sizeof(double)), *fld2 = (double *)calloc((size_t)rows * 19, sizeof(double));
+  double *tmp = (double *)calloc(ncell, sizeof(double));
+  int32_t *icnt = (int32_t *)calloc(ncell, sizeof(int32_t));
+  static const int src[16] = {KID_B_LON, KID_B_LAT, KID_B_UVEL, KID_B_VVEL, KID_B_MASS, KID_B_THICKNESS, KID_B_WIDTH, KID_B_LENGTH,
+                              KID_B_AXN, KID_B_AYN, KID_B_BXN, KID_B_BYN, KID_B_UVEL_OLD, KID_B_VVEL_OLD, KID_B_LON_OLD, KID_B_LAT_OLD};
+  uint32_t ichk5 = 0;
+  int64_t q = 0;
+  for (int gj = d->jsc; gj <= d->jec; ++gj)
+    for (int gi = d->isc; gi <= d->iec; ++gi) {
+      int64_t i = 0; ichk5 = 0;
+      /* perm is sorted by (jne, ine, inorder): skip what lies before this cell (dead rows, rows outside the domain) */
+      while (q < b->n && (b->i32[KID_BI_JNE][perm[q]] < gj || (b->i32[KID_BI_JNE][perm[q]] == gj && b->i32[KID_BI_INE][perm[q]] < gi))) ++q;
+      for (; q < b->n && b->i32[KID_BI_JNE][perm[q]] == gj && b->i32[KID_BI_INE][perm[q]] == gi; ++q) {
+        const int64_t k = perm[q];
+        if (!berg_alive(b, k)) continue;
+        const int32_t iberg = one_berg_chksum(b, k);
+        const double sy = (double)(b->i32[KID_BI_START_YEAR] ? b->i32[KID_BI_START_YEAR][k] : 0);
+        const double time_hash = b->f64[KID_B_START_DAY][k] + 366. * sy;
+        const double pos_hash = b->f64[KID_B_START_LON][k] + 360. * (b->f64[KID_B_START_LAT][k] + 90.);
+        double *row = fld + (size_t)i * 19;
+        for (int c = 0; c < 16; ++c) row[c] = b->f64[src[c]] ? b->f64[src[c]][k] : 0.;
+        row[16] = time_hash; row[17] = pos_hash; row[18] = (double)iberg;
+        const size_t cc = GIDX(g, gi, gj);
+        icnt[cc] += 1;
+        for (int c = 0; c < 19; ++c) fld2[(size_t)i * 19 + c] = row[c] * (double)icnt[cc];
+        tmp[cc] = tmp[cc] + time_hash * pos_hash + log(b->f64[KID_B_MASS][k]);
+        ichk5 += (uint32_t)iberg;
+        ++i;
+      }
+    }
+  uint64_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  for (int64_t c = 0; c < rows * 19; ++c) { s1 += dbits(fld[c]); s2 += dbits(fld2[c]); }
+  for (int gj = d->jsd; gj <= d->jed; ++gj)
+    for (int gi = d->isd; gi <= d->ied; ++gi) {
+      const uint64_t u = dbits(tmp[GIDX(g, gi, gj)]);
+      s3 += u;
+      if (gi >= d->isc && gi <= d->iec && gj >= d->jsc && gj <= d->jec) s4 += u;
+    }
+  out[0] = (int32_t)(uint32_t)s1; out[1] = (int32_t)(uint32_t)s2; out[2] = (int32_t)(uint32_t)s3; out[3] = (int32_t)(uint32_t)s4;
+  out[4] = (int32_t)ichk5; out[5] = nb;
+  free(perm); free(fld); free(fld2); free(tmp); free(icnt);
+}

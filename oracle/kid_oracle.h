@@ -80,6 +80,8 @@ int64_t ko_get_fl_step(void);
  * acc: KID_NACC fields of (ied-isd+1)*(jed-jsd+1); out: KID_NOUT fields; scalars: KID_NSCALAR. */
 void ko_run_step(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
                  double *acc, double *out, double *scalars);
+/* bergs_chksum FW:6889-6987 (+ berg_chksum, time_hash, pos_hash, FMS mpp_chksum): chksum, chksum2, chksum3, chksum4, chksum5, # */
+void ko_bergs_chksum(const ko_grid *g, const kid_berg_soa *b, int64_t out[6]);
 /* reference traversal order: permutation sorted by (jne, ine, inorder-key) */
 void ko_reference_order(const kid_berg_soa *b, int64_t *perm);
 /* berg migration between sub-domains: send_bergs_to_other_pes FW:2997-3247, pack / unpack FW:3250-3301, 3455-3680 */

@@ -82,6 +82,8 @@ def load():
     lib.ko_thermodynamics.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
     lib.ko_create_gridded_icebergs_fields.restype = None
     lib.ko_create_gridded_icebergs_fields.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
+    lib.ko_bergs_chksum.restype = None
+    lib.ko_bergs_chksum.argtypes = [C.POINTER(KoGrid), C.POINTER(T.BergSoA), C.POINTER(C.c_int64)]
     lib.ko_philox4x32_10.restype = None
     lib.ko_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ko_fl_uniform.restype = d; lib.ko_fl_uniform.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.c_int32]
@@ -257,6 +259,13 @@ class Oracle:
         lost = self.lib.ko_unpack_bergs(C.byref(self.kg), C.byref(self.params), C.byref(s), _dp(buf), len(buf)) if len(buf) else 0
         bergs["_n"] = int(s.n)
         return int(lost)
+
+    def bergs_chksum(self, bergs):
+        """(chksum, chksum2, chksum3, chksum4, chksum5, #) of bergs_chksum (FW:6889-6987)"""
+        s = self.soa(bergs)
+        out = (C.c_int64 * 6)()
+        self.lib.ko_bergs_chksum(C.byref(self.kg), C.byref(s), out)
+        return tuple(int(v) for v in out)
 
     def step_local(self, bergs):
         s = self.soa(bergs)

@@ -2,7 +2,7 @@
 
   hexagon_test            /root/reference/src/icebergs.F90:247-353
   point_in_triangle_test  /root/reference/src/icebergs.F90:226-244
-  basal_melt_test         /root/reference/src/icebergs.F90:205-223 (printed values recorded in SURVEY.md sec. 4)
+  basal_melt_test         /root/reference/src/icebergs.F90:205-223 (inputs only; the printed values are a survey probe, not reference-held)
   unit_tests (bilin)      /root/reference/src/icebergs_framework.F90:7299-7327
 """
 import ctypes as C
@@ -64,8 +64,9 @@ def test_point_in_triangle_test(oracle):
 
 
 def test_basal_melt_test(oracle):
-    """IB:214: dvo=0.2, lat=0, salt=35, temp=2, thickness=100 with namelist defaults.
-    Printed values of the compiled reference recorded in SURVEY.md section 4."""
+    """IB:214: dvo=0.2, lat=0, salt=35, temp=2, thickness=100 with namelist defaults (the inputs are reference-held).
+    The two values are NOT a reference-held pin: the reference only prints them; the survey recorded them from a probe build
+    against stand-in FMS modules.  Kept as a regression value of the oracle."""
     p = S.default_params()
     d = T.GridDesc()
     d.grid_is_latlon = 1

@@ -74,7 +74,7 @@ def test_c2_latlon(oracle, continents):
     """BASELINE config 2 at an oracle-sized population: lat-lon 360x200 (calc_xiyj path), RK4, melt,
     rectangular mass spreading; `continents` adds land rectangles so that bergs bounce off coasts."""
     grid, p, b = S.config_c2(n=40000, seed=2, continents=continents)
-    ref, got = _both(grid, p, b, 12, "fused")
+    ref, got = _both(grid, p, b, 48, "fused")   # SURVEY 8d: 48 steps of 1800 s (one model day)
     P.compare(ref, got, "C2/continents=%s" % continents, params=p)
 
 

@@ -19,21 +19,16 @@ module kid_hip_mod
   public :: kid_grid_desc, kid_params, kid_berg_soa
   public :: kid_create, kid_destroy, kid_set_params, kid_sync, kid_set_static_grid, kid_set_forcing
   public :: kid_upload_bergs, kid_download_bergs, kid_num_bergs, kid_compact_bergs
-  public :: kid_forcing_in, kid_ingest_forcing, kid_get_forcing, KID_BGRID_NE, KID_CGRID_NE, KID_AGRID
+  public :: kid_forcing_in, kid_ingest_forcing, kid_get_forcing
   public :: kid_calving_params, kid_calving_in, kid_set_calving_params, kid_set_calving_state, kid_get_calving_state
-  public :: kid_calving, kid_get_calving, KID_NCALV_SCALARS, KID_NCLASSES
+  public :: kid_calving, kid_get_calving
   public :: kid_write_restart, kid_read_restart, kid_bergs_chksum
-  public :: kid_buffer_width, kid_pack_emigrants, kid_unpack_immigrants, kid_pack_emigrants_pair, kid_unpack_immigrants_pair, KID_DIR_E, KID_DIR_W, KID_DIR_N, KID_DIR_S
+  public :: kid_buffer_width, kid_pack_emigrants, kid_unpack_immigrants, kid_pack_emigrants_pair, kid_unpack_immigrants_pair
   public :: kid_traj_params, kid_set_traj_params, kid_record_posn, kid_write_trajectories, kid_write_bond_trajectories
   public :: kid_zero_accumulators, kid_interp_gridded_fields_to_bergs, kid_evolve_icebergs, kid_footloose_calving
   public :: kid_set_footloose_step, kid_get_footloose_step
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
-  public :: KID_NGRID_STATIC, KID_NFORCING, KID_NB_F64, KID_NB_I32, KID_NACC, KID_NOUT, KID_NSCALAR
-  public :: KID_B_LON, KID_B_LAT, KID_B_UVEL, KID_B_VVEL, KID_B_MASS, KID_B_THICKNESS, KID_B_WIDTH, KID_B_LENGTH
-  public :: KID_B_XI, KID_B_YJ, KID_BI_INE, KID_BI_JNE, KID_BI_ALIVE
-  public :: KID_A_FLOATING_MELT, KID_A_BERG_MELT, KID_A_CALVING_HFLX, KID_O_SPREAD_MASS
-  public :: KID_S_NET_HEAT_TO_OCEAN, KID_S_NBERGS_MELTED, KID_S_NBERGS_ALIVE
 
   interface
     integer(c_int) function kid_create(grid, params, capacity, device, handle) bind(C, name='kid_create')

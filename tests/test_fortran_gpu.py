@@ -226,3 +226,129 @@ def test_fortran_coupling_front_end(oracle, tmp_path, staggers):
         assert np.array_equal(f.variables["stored_ice"][0], g_ice[:, sl[0], sl[1]]) and np.array_equal(f.variables["stored_heat"][0], g_heat[sl])
     with netcdf_file(str(rdir / "iceberg_trajectories.nc"), "r", mmap=False) as f:
         assert f.variables["lon"].shape == (int(ga.sum()),) and list(f.variables)[:6] == ["lon", "lat", "year", "day", "id_cnt", "id_ij"]
+
+
+GLUE = os.path.join(ROOT, "icebergs_amd", "fortran", "kid_glue_test")
+MAGIC3 = 1263093764
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("staggers", [("B", "B"), ("C", "A")])
+def test_glue_lists_and_icebergs_run(oracle, tmp_path, staggers):
+    """icebergs_amd/fortran/kid_icebergs_glue.F90 through its self-contained driver: linked lists of `iceberg` nodes per
+    cell are built by sorted insertion (`inorder`, FW:4318-4359) from a SHUFFLED population, flattened in the reference's
+    traversal order (cells j outer / i inner, list order: SURVEY A13), stepped four times through the argument list of
+    icebergs_run (forcing ingest + calving + hot path + the coupler return of IB:5654-5679), and rebuilt from the device.
+    Checked: the flattening order is the reference's; the calving / calving_hflx / mass_berg handed back to the coupler and
+    the bergs of the rebuilt lists equal the oracle's; the rebuilt lists are sorted (the driver checks with `inorder`)."""
+    import oracle_lib as O
+    subprocess.run(["make", "-s", "-C", os.path.dirname(GLUE)], check=True)
+    vs, ss = staggers
+    grid = S.c2_forcing(S.latlon_grid(ni=60, nj=200, dlon=6.0))
+    p = S.default_params()
+    p.current_year, p.current_yearday = 3, 41.5
+    b = S.place_bergs(grid, 400, 6, (3, 57), (3, 197))
+    rng = np.random.default_rng(12)
+    n = len(b["lon"])
+    b["ine"][:150] = 30                              # long lists: 150 bergs share four cells
+    b["jne"][:150] = rng.integers(100, 104, 150)
+    d, st = grid["desc"], grid["static"]
+    for k in range(150):                             # (keep them inside the cells they were moved to)
+        jj, ii = b["jne"][k] - d.jsd, b["ine"][k] - d.isd
+        b["xi"][k], b["yj"][k] = rng.uniform(0.2, 0.8, 2)
+        b["lon"][k] = st["lon"][jj, ii - 1] + b["xi"][k] * (st["lon"][jj, ii] - st["lon"][jj, ii - 1])
+        b["lat"][k] = st["lat"][jj - 1, ii] + b["yj"][k] * (st["lat"][jj, ii] - st["lat"][jj - 1, ii])
+        b["lon_old"][k], b["lat_old"][k], b["start_lon"][k], b["start_lat"][k] = b["lon"][k], b["lat"][k], b["lon"][k], b["lat"][k]
+    b["start_year"][:] = rng.integers(1, 3, n)
+    b["start_day"][:] = np.round(rng.uniform(0, 50, n))       # ties on the second key: the later keys decide
+    perm = rng.permutation(n)
+    shuffled = {k: (v[perm].copy() if hasattr(v, "dtype") and len(v) == n else v) for k, v in b.items()}
+    cp = S.calving_params(p)
+    ncalls, cap = 4, 12000
+    st_code = {"B": T.ENUMS["KID_BGRID_NE"], "C": T.ENUMS["KID_CGRID_NE"], "A": T.ENUMS["KID_AGRID"]}
+    calls = []
+    for k in range(ncalls):
+        a = S.coupler_forcing(grid, seed=40 + k, vel_stagger=vs, stress_stagger=ss, kelvin=(k % 2 == 1), sss=True)
+        a["calving"], a["calving_hflx"] = S.coupler_calving(grid, seed=k % 2, frac=0.04)
+        calls.append(a)
+    case, res = str(tmp_path / "glue.bin"), str(tmp_path / "glue_res.bin")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<i", MAGIC3))
+        f.write(bytes(grid["desc"])); f.write(bytes(p)); f.write(bytes(cp))
+        f.write(struct.pack("<6i", st_code[vs], st_code[ss], 0, 1, 1, ncalls))
+        a0 = calls[0]
+        f.write(struct.pack("<8i", a0["uo"].shape[1], a0["uo"].shape[0], a0["vo"].shape[1], a0["vo"].shape[0],
+                            a0["tauxa"].shape[1], a0["tauxa"].shape[0], a0["tauya"].shape[1], a0["tauya"].shape[0]))
+        f.write(struct.pack("<qq", n, cap))
+        for name in T.GRID_STATIC_NAMES:
+            f.write(np.ascontiguousarray(grid["static"][name], dtype=np.float64).tobytes())
+        for name in T.BERG_F64_NAMES:
+            f.write(shuffled[name].tobytes())
+        for name in T.BERG_I32_NAMES:
+            f.write(shuffled[name].tobytes())
+        f.write(shuffled["id"].tobytes())
+        for a in calls:
+            for name in ("uo", "ui", "vo", "vi", "tauxa", "tauya", "ssh", "cn", "hi", "sst", "sss", "calving", "calving_hflx"):
+                f.write(np.ascontiguousarray(a[name], dtype=np.float64).tobytes())
+    r = subprocess.run([GLUE, case, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    # the same sequence on the oracle
+    orc = O.Oracle(grid, p)
+    stc = orc.new_calving_state()
+    bergs = S.empty_bergs(cap)
+    for k_, v in b.items():
+        bergs[k_][:n] = v
+    bergs["alive"][n:] = 0
+    bergs["_n"] = n
+    planes, want_calv, want_hflx = None, [], []
+    nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+    sl = (slice(d.jsc - d.jsd, d.jec - d.jsd + 1), slice(d.isc - d.isd, d.iec - d.isd + 1))
+    area = st["area"][sl]
+    for a in calls:
+        planes = orc.ingest_forcing(a, vel_stagger=vs, stress_stagger=ss, cyclic_x=True, planes=planes)
+        orc.set_forcing(planes)
+        rc, _ = orc.calving(cp, a["calving"], a["calving_hflx"], stc, bergs, cap)
+        assert rc == 0
+        orc.run_step(bergs, 1)
+        fm = orc.acc[T.ACC_NAMES["floating_melt"]][sl]
+        want_calv.append(np.where(area > 0, stc["calving"][sl] / np.where(area > 0, area, 1.0) + fm, 0.0))      # IB:5654-5660
+        want_hflx.append(stc["calving_hflx"][sl] + orc.acc[T.ACC_NAMES["calving_hflx"]][sl])                    # IB:3129, 5661
+    want_mass = orc.out[T.OUT_NAMES["spread_mass"]][sl]
+    with open(res, "rb") as f:
+        m0 = struct.unpack("<q", f.read(8))[0]
+        flat_ids = np.frombuffer(f.read(8 * m0), dtype=np.int64).copy()
+        got_calv, got_hflx = [], []
+        for _ in range(ncalls):
+            got_calv.append(np.frombuffer(f.read(8 * nic * njc), dtype=np.float64).reshape(njc, nic).copy())
+            got_hflx.append(np.frombuffer(f.read(8 * nic * njc), dtype=np.float64).reshape(njc, nic).copy())
+        got_mass = np.frombuffer(f.read(8 * nic * njc), dtype=np.float64).reshape(njc, nic).copy()
+        m = struct.unpack("<q", f.read(8))[0]
+        gb = {name: np.frombuffer(f.read(8 * m), dtype=np.float64).copy() for name in T.BERG_F64_NAMES}
+        for name in T.BERG_I32_NAMES:
+            gb[name] = np.frombuffer(f.read(4 * m), dtype=np.int32).copy()
+        gb["id"] = np.frombuffer(f.read(8 * m), dtype=np.int64).copy()
+    # A13: the order the glue flattened the lists in = cells j outer / i inner, `inorder` inside a cell
+    want_order = sorted(range(n), key=lambda k: (b["jne"][k], b["ine"][k], b["start_year"][k], b["start_day"][k], b["start_mass"][k], b["start_lon"][k], b["start_lat"][k]))
+    assert m0 == n and np.array_equal(flat_ids, b["id"][want_order])
+    # ... and the oracle's own notion of that order
+    perm2 = np.zeros(n, dtype=np.int64)
+    soa = orc.soa({k: (v[:n] if hasattr(v, "dtype") else v) for k, v in b.items() if k != "_n"})
+    orc.lib.ko_reference_order(C.byref(soa), perm2.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert np.array_equal(b["id"][perm2], flat_ids)
+    # what went back to the coupler
+    for k in range(ncalls):
+        assert np.allclose(got_calv[k], want_calv[k], rtol=1e-9, atol=1e-9 * np.abs(want_calv[k]).max()), k
+        assert np.allclose(got_hflx[k], want_hflx[k], rtol=1e-9, atol=1e-9 * max(np.abs(want_hflx[k]).max(), 1e-300)), k
+    assert np.allclose(got_mass, want_mass, rtol=1e-9, atol=1e-9 * np.abs(want_mass).max())
+    # the rebuilt lists hold the oracle's survivors
+    ra = bergs["alive"][:bergs["_n"]] != 0
+    assert m == int(ra.sum()) and m > n + 200
+    ro, go = np.argsort(bergs["id"][:bergs["_n"]][ra]), np.argsort(gb["id"])
+    assert np.array_equal(bergs["id"][:bergs["_n"]][ra][ro], gb["id"][go])
+    for name in ("lon", "lat", "uvel", "vvel", "mass", "thickness", "width", "length", "heat_density", "start_day", "xi", "yj"):
+        rv, gv = bergs[name][:bergs["_n"]][ra][ro], gb[name][go]
+        assert np.allclose(gv, rv, rtol=1e-10, atol=1e-12), (name, float(np.abs(gv - rv).max()))
+    # and come out of the lists in traversal order again
+    key = list(zip(gb["jne"].tolist(), gb["ine"].tolist(), gb["start_year"].tolist(), gb["start_day"].tolist(), gb["start_mass"].tolist(),
+                   gb["start_lon"].tolist(), gb["start_lat"].tolist()))
+    assert key == sorted(key)

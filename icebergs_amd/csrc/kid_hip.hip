@@ -362,7 +362,8 @@ struct kid_handle {
   int32_t *d_traj_year = nullptr, *d_traj_nbonds = nullptr; unsigned long long *d_traj_cursor = nullptr; long long traj_capacity = 0, traj_count_bound = 0; int traj_nf = 0;
   double *d_mig_buf = nullptr; long long mig_capacity = 0; unsigned long long *mig_word = nullptr;   // pinned staging of kid_pack_emigrants / kid_unpack_immigrants
   double *d_btraj_f[16] = {}; int64_t *d_btraj_id[2] = {}; int32_t *d_btraj_i[2] = {}; long long btraj_capacity = 0, btraj_count_bound = 0;   // bond samples
-  double *d_spread_mass_old = nullptr;   // grd%spread_mass_old (find_melt_using_spread_mass, IB:5495-5497)
+  double *d_spread_mass_old = nullptr;   // grd%spread_mass_old (find_melt_using_spread_mass, IB:5495-5497) + spread_mass_tmp; the handle's own or the caller's (kid_bind_spread_mass_old)
+  double *d_spread_mass_old_own = nullptr;
   bool have_static = false, have_forcing = false, have_planes = false;  // have_planes: d_forcing holds all eleven planes
   double *d_calv_state = nullptr, *d_calv_scal = nullptr, *d_calv_part = nullptr; unsigned char *d_calv_flag = nullptr; int2 *d_calv_list = nullptr; double *calv_host = nullptr; kid_calving_params calv_params{};  // kid_calving (kid_calving.inc)
   bool calving_on = false, calving_first_call = true, rmean_init = false, rmean_hflx_init = false;
@@ -563,7 +564,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_trc2) (void)hipFree(h->d_trc2);
   if (h->d_lane) (void)hipFree(h->d_lane);
   if (h->d_lane_alt) (void)hipFree(h->d_lane_alt);
-  if (h->d_spread_mass_old) (void)hipFree(h->d_spread_mass_old);
+  if (h->d_spread_mass_old_own) (void)hipFree(h->d_spread_mass_old_own);
   for (auto &q : h->d_traj_f) if (q) (void)hipFree(q);
   if (h->d_traj_day) (void)hipFree(h->d_traj_day);
   if (h->d_traj_id) (void)hipFree(h->d_traj_id);
@@ -1372,7 +1373,11 @@ int kid_step_local(kid_handle *h) {
     // IB:5490-5503: the gridded mass BEFORE the thermodynamics (calculate_mass_on_ocean without diagnostics, the 'mass'
     // gather into grd%spread_mass_old, planes reset), then thermodynamics + create_gridded_icebergs_fields as usual; the
     // gather replaces floating_melt by (spread_mass_old - spread_mass)/dt (IB:3436-3445)
-    if (!h->d_spread_mass_old) { KID_HIP(h, hipMalloc(&h->d_spread_mass_old, 2 * h->ncell * sizeof(double))); KID_HIP(h, hipMemsetAsync(h->d_spread_mass_old, 0, 2 * h->ncell * sizeof(double), h->stream)); }  // + spread_mass_tmp
+    if (!h->d_spread_mass_old) {
+      KID_HIP(h, hipMalloc(&h->d_spread_mass_old_own, 2 * h->ncell * sizeof(double)));   // + spread_mass_tmp
+      KID_HIP(h, hipMemsetAsync(h->d_spread_mass_old_own, 0, 2 * h->ncell * sizeof(double), h->stream));
+      h->d_spread_mass_old = h->d_spread_mass_old_own;
+    }
     if (!p.static_icebergs) { rc = p.old_interp_flds_order ? launch_berg<PH_EVOLVE>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h); if (rc) return rc; }
     const size_t on_ocean = (size_t)KID_A_MASS_ON_OCEAN * h->ncell, on_bytes = 36 * h->ncell * sizeof(double);
     KID_HIP(h, hipMemsetAsync(h->d_acc + on_ocean, 0, on_bytes, h->stream));
@@ -1466,6 +1471,13 @@ int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count) {
   return KID_OK;
 }
 
+int kid_bind_spread_mass_old(kid_handle *h, void *dev_ptr, int64_t count) {
+  if (!h) return KID_EINVAL;
+  if (!dev_ptr) { h->d_spread_mass_old = h->d_spread_mass_old_own; return KID_OK; }
+  if (count < (int64_t)(2 * h->ncell)) { h->err = "spread_mass_old buffer too small (2 planes)"; return KID_EINVAL; }
+  h->d_spread_mass_old = (double *)dev_ptr;
+  return KID_OK;
+}
 int kid_last_redo_count(kid_handle *h, int64_t *count) {
   if (!h || !count) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));

@@ -38,8 +38,6 @@ def needs_footprint_planes(params):
 
 def accumulator_views(acc_block, ncell, diag_mask=0, params=None):
     """(planes that must be reduced, scalar increments) as views of the contiguous accumulator block."""
-    if params is not None and params.find_melt_using_spread_mass:
-        raise NotImplementedError("find_melt_using_spread_mass needs grd%spread_mass_old summed over the ranks too: single-GPU only")
     diag_planes = sum(T.ENUMS[k] for k in (
         "KID_DIAG_MELT_BY_CLASS", "KID_DIAG_FL_PARENT_MELT", "KID_DIAG_FL_CHILD_MELT", "KID_DIAG_MELT_BUOY",
         "KID_DIAG_MELT_EROS", "KID_DIAG_MELT_CONV", "KID_DIAG_MELT_BUOY_FL", "KID_DIAG_MELT_EROS_FL",
@@ -53,14 +51,28 @@ def accumulator_views(acc_block, ncell, diag_mask=0, params=None):
     return acc_block[: nplanes * ncell], acc_block[T.NACC * ncell: T.NACC * ncell + T.NSCALAR]
 
 
+def needs_spread_mass_old(params):
+    """find_melt_using_spread_mass (IB:5490-5503): the melt flux is what the GRIDDED mass lost over the step, so the gridded
+    mass before the thermodynamics (grd%spread_mass_old; with Iceberg_melt_without_decay also spread_mass_tmp, IB:3411-3413)
+    is part of what the ranks must sum: two more planes, 9-point gathers of per-cell sums and therefore linear in every
+    rank's contribution, reduced between the local work and the gather together with the accumulator planes."""
+    return params is not None and bool(params.find_melt_using_spread_mass)
+
+
 class ShardedStepper:
     """One coupling step of the sharded path: local per-berg work, all-reduce, local gather.
 
     `backend` is anything with step_local() / step_gather() that accumulates into `acc_block` (a torch tensor:
     device memory bound to the HIP handle in production, host memory in the gloo tests)."""
 
-    def __init__(self, backend, acc_block, ncell, diag_mask=0, dist=None, resort_interval=16, params=None, force_collective=False):
+    def __init__(self, backend, acc_block, ncell, diag_mask=0, dist=None, resort_interval=16, params=None, force_collective=False,
+                 spread_mass_old=None):
+        """spread_mass_old: with find_melt_using_spread_mass, the 2-plane tensor the backend was told to keep grd%spread_mass_old /
+        spread_mass_tmp in (kid_bind_spread_mass_old on the HIP handle)"""
         self.backend = backend
+        self.spread_mass_old = spread_mass_old if needs_spread_mass_old(params) else None
+        if needs_spread_mass_old(params) and spread_mass_old is None:
+            raise ValueError("find_melt_using_spread_mass: pass the tensor bound with kid_bind_spread_mass_old (2 planes)")
         self.resort_interval = resort_interval
         self._since_sort = 0
         self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
@@ -77,6 +89,8 @@ class ShardedStepper:
         if self.dist is not None:
             self.dist.all_reduce(self.planes)
             self.dist.all_reduce(self.scalars)
+            if self.spread_mass_old is not None:
+                self.dist.all_reduce(self.spread_mass_old)
         self.backend.step_gather()
         self._since_sort += 1
         if self.resort_interval and self._since_sort >= self.resort_interval and hasattr(self.backend, "move_berg_between_cells"):
@@ -100,6 +114,8 @@ class PipelinedStepper:
     def __init__(self, ib, params, dist=None, resort_interval=16, force_collective=False, split_general=False, slow_lane=False):
         import torch
         self.torch, self.ib, self.params = torch, ib, params
+        if needs_spread_mass_old(params):
+            raise NotImplementedError("find_melt_using_spread_mass: use ShardedStepper (its gather needs this step's summed planes, there is nothing to overlap)")
         self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
         self.dev = torch.device("cuda", ib.device)
         _, self.count = ib.accum_device_ptr()

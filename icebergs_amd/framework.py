@@ -412,6 +412,10 @@ class Icebergs:
     def bind_accum_buffer(self, ptr, count):
         self._check(self.lib.kid_bind_accum_buffer(self.h, C.c_void_p(ptr), int(count)), "kid_bind_accum_buffer")
 
+    def bind_spread_mass_old(self, ptr, count):
+        """find_melt_using_spread_mass in a sharded run: the two planes the ranks must sum (include/kid.h)"""
+        self._check(self.lib.kid_bind_spread_mass_old(self.h, ptr, int(count)), "kid_bind_spread_mass_old")
+
     def last_redo_count(self):
         c = C.c_int64()
         self._check(self.lib.kid_last_redo_count(self.h, C.byref(c)), "kid_last_redo_count")

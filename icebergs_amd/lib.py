@@ -18,7 +18,7 @@ SYMBOLS = [
     "kid_num_bergs", "kid_compact_bergs", "kid_move_berg_between_cells", "kid_set_resort_interval", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
     "kid_evolve_icebergs", "kid_footloose_calving", "kid_set_footloose_step", "kid_get_footloose_step", "kid_footloose_uniform", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
     "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
-    "kid_bind_accum_buffer", "kid_profile_enable", "kid_profile_get",
+    "kid_bind_accum_buffer", "kid_bind_spread_mass_old", "kid_profile_enable", "kid_profile_get",
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
     "kid_ingest_forcing", "kid_get_forcing",
     "kid_set_calving_params", "kid_set_calving_state", "kid_get_calving_state", "kid_calving", "kid_get_calving",
@@ -120,6 +120,7 @@ def load():
     lib.kid_get_accumulators.argtypes = [H, dp, dp, dp]
     lib.kid_accum_device_ptr.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.kid_bind_accum_buffer.argtypes = [H, C.c_void_p, C.c_int64]
+    lib.kid_bind_spread_mass_old.argtypes = [H, C.c_void_p, C.c_int64]
     lib.kid_profile_enable.argtypes = [H, C.c_int]
     lib.kid_profile_get.argtypes = [H, dp, C.POINTER(C.c_int64), dp]
     for name in SYMBOLS:

@@ -245,6 +245,12 @@ int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalar
 int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count);
 /* Use caller-owned device memory (e.g. a torch tensor) for the accumulator block instead. */
 int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count);
+/* find_melt_using_spread_mass (IB:5490-5503): grd%spread_mass_old -- the gridded mass before the thermodynamics -- and, with
+ * Iceberg_melt_without_decay, spread_mass_tmp (IB:3411-3413) live in two planes that kid_step_local fills and kid_step_gather
+ * reads.  Both are 9-point gathers of per-cell sums, i.e. linear in what each GPU's bergs contribute: a sharded run binds a
+ * buffer of its own here (2 planes of ni*nj fp64) and all-reduces it between kid_step_local and kid_step_gather together with
+ * the accumulator planes.  NULL returns to the handle's own planes. */
+int kid_bind_spread_mass_old(kid_handle *h, void *dev_ptr, int64_t count);
 
 /* ---- measurement: HIP-event timing of the per-berg kernel on the launch stream ---- */
 int kid_profile_enable(kid_handle *h, int on);

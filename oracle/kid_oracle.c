@@ -1474,7 +1474,16 @@ void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_
  * follows the all-reduce of the accumulators. */
 static const double *g_spread_mass_tmp = NULL;   /* spread_mass_tmp of IB:3411-3413 (Iceberg_melt_without_decay) */
 static const double *g_spread_mass_old = NULL;   /* grd%spread_mass_old while ko_run_step runs with find_melt_using_spread_mass */
+static double *g_shard_spread_mass = NULL;   /* see ko_set_spread_mass_buffer */
+static void gather_fields_core(const ko_grid *g, const kid_params *p, double *acc, double *out);
 void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double *out) {
+  const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
+  const int shard = p->find_melt_using_spread_mass && g_shard_spread_mass && !g_spread_mass_old;
+  if (shard) { g_spread_mass_old = g_shard_spread_mass; g_spread_mass_tmp = p->Iceberg_melt_without_decay ? g_shard_spread_mass + ncell : NULL; }
+  gather_fields_core(g, p, acc, out);
+  if (shard) { g_spread_mass_old = NULL; g_spread_mass_tmp = NULL; }
+}
+static void gather_fields_core(const ko_grid *g, const kid_params *p, double *acc, double *out) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
   const int dm = p->diag_mask;
   double *o_mass = out + (size_t)KID_O_SPREAD_MASS * ncell, *o_area = out + (size_t)KID_O_SPREAD_AREA * ncell;
@@ -1539,6 +1548,9 @@ void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, ki
   ko_gather_fields(g, p, acc, out);
 }
 /* everything of one step that is per berg (the part a rank does on its own shard); accumulators zeroed first */
+/* Sharded runs with find_melt_using_spread_mass: the caller's two planes for grd%spread_mass_old and spread_mass_tmp, filled
+ * by ko_step_local from THIS shard's bergs, summed over the ranks by the caller, read by ko_gather_fields. */
+void ko_set_spread_mass_buffer(double *two_planes) { g_shard_spread_mass = two_planes; }
 void ko_step_local(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity, double *acc, double *scalars) {
   const size_t ncell = (size_t)NI(g) * (size_t)(g->d.jed - g->d.jsd + 1);
   memset(acc, 0, (size_t)KID_NACC * ncell * sizeof(double));
@@ -1546,7 +1558,19 @@ void ko_step_local(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64
   if (!p->static_icebergs) ko_evolve_icebergs(g, p, b, scalars);
   if (p->footloose) ko_footloose_calving(g, p, b, capacity, acc, scalars);
   if (!p->old_interp_flds_order) ko_interp_gridded_fields_to_bergs(g, p, b);
+  const int fm = p->find_melt_using_spread_mass && g_shard_spread_mass;
+  if (fm) {  /* IB:5490-5503, this shard's share */
+    g_mass_only = 1; ko_calculate_mass_on_ocean(g, p, b, acc); g_mass_only = 0;
+    memset(g_shard_spread_mass, 0, 2 * ncell * sizeof(double));
+    g_wrap_x = p->periodic_reentry && g->d.Lx > 0.;
+    sum_up_spread_field(g, acc, KID_A_MASS_ON_OCEAN, 0, g_shard_spread_mass);
+    for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
+  }
   ko_thermodynamics(g, p, b, acc, scalars);
+  if (fm && p->Iceberg_melt_without_decay) {  /* IB:3411-3413 */
+    sum_up_spread_field(g, acc, KID_A_MASS_ON_OCEAN, 0, g_shard_spread_mass + ncell);
+    for (int s = 0; s < 36; ++s) memset(acc + (size_t)(KID_A_MASS_ON_OCEAN + s) * ncell, 0, ncell * sizeof(double));
+  }
   ko_calculate_mass_on_ocean(g, p, b, acc);
 }
 /* one icebergs_run() worth of the hot path, IB:5423-5512 (non-MTS, non-interactive) */

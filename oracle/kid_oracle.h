@@ -65,6 +65,9 @@ void ko_create_gridded_icebergs_fields(const ko_grid *g, const kid_params *p, ki
 void ko_calculate_mass_on_ocean(const ko_grid *g, const kid_params *p, kid_berg_soa *b, double *acc);
 void ko_gather_fields(const ko_grid *g, const kid_params *p, double *acc, double *out);
 void ko_step_local(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity, double *acc, double *scalars);
+/* sharded find_melt_using_spread_mass: two planes (spread_mass_old, spread_mass_tmp) that ko_step_local fills from its shard,
+ * the caller sums over the ranks and ko_gather_fields reads; NULL switches back */
+void ko_set_spread_mass_buffer(double *two_planes);
 void ko_footloose_calving(const ko_grid *g, const kid_params *p, kid_berg_soa *b, int64_t capacity,
                           double *acc, double *scalars);
 void ko_meters_to_grid(const ko_grid *g, const kid_params *p, double lat_ref, double *dlon_dx, double *dlat_dy);

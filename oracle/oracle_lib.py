@@ -82,6 +82,8 @@ def load():
     lib.ko_thermodynamics.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
     lib.ko_create_gridded_icebergs_fields.restype = None
     lib.ko_create_gridded_icebergs_fields.argtypes = [C.POINTER(KoGrid), C.POINTER(T.Params), C.POINTER(T.BergSoA), C.POINTER(d), C.POINTER(d)]
+    lib.ko_set_spread_mass_buffer.restype = None
+    lib.ko_set_spread_mass_buffer.argtypes = [C.POINTER(d)]
     lib.ko_bergs_chksum.restype = None
     lib.ko_bergs_chksum.argtypes = [C.POINTER(KoGrid), C.POINTER(T.BergSoA), C.POINTER(C.c_int64)]
     lib.ko_philox4x32_10.restype = None
@@ -266,6 +268,11 @@ class Oracle:
         out = (C.c_int64 * 6)()
         self.lib.ko_bergs_chksum(C.byref(self.kg), C.byref(s), out)
         return tuple(int(v) for v in out)
+
+    def set_spread_mass_buffer(self, two_planes):
+        """sharded find_melt_using_spread_mass: the array the ranks sum between step_local and step_gather (None: off)"""
+        self._spread_buf = two_planes
+        self.lib.ko_set_spread_mass_buffer(_dp(two_planes) if two_planes is not None else None)
 
     def step_local(self, bergs):
         s = self.soa(bergs)

@@ -28,13 +28,15 @@ class OracleBackend:
         self.o.step_gather()
 
 
-def _worker(rank, world, port, nbergs, nsteps, out_dir):
+def _worker(rank, world, port, nbergs, nsteps, out_dir, find_melt=0):
     import oracle_lib
     from icebergs_amd import synthetic as S, distributed as D, types as T
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     grid, p, b = S.config_c2(n=nbergs, seed=17, continents=True)
+    p.find_melt_using_spread_mass = 1 if find_melt else 0
+    p.Iceberg_melt_without_decay = 1 if find_melt == 2 else 0
     mine = D.take_shard(b, rank, world)
     o = oracle_lib.Oracle(grid, p)
     ncell = o.ni * o.nj
@@ -42,7 +44,12 @@ def _worker(rank, world, port, nbergs, nsteps, out_dir):
     block = np.zeros(T.NACC * ncell + T.NSCALAR)
     o.acc = block[: T.NACC * ncell].reshape(T.NACC, o.nj, o.ni)
     o.scalars = block[T.NACC * ncell:]
-    stepper = D.ShardedStepper(OracleBackend(o, mine), torch.from_numpy(block), ncell, p.diag_mask, dist, params=p)
+    spread_old = None
+    if find_melt:   # grd%spread_mass_old (+ spread_mass_tmp): two more planes the ranks sum
+        spread_old = np.zeros(2 * ncell)
+        o.set_spread_mass_buffer(spread_old)
+    stepper = D.ShardedStepper(OracleBackend(o, mine), torch.from_numpy(block), ncell, p.diag_mask, dist, params=p,
+                               spread_mass_old=(torch.from_numpy(spread_old) if find_melt else None))
     totals = np.zeros(T.NSCALAR)
     for _ in range(nsteps):
         o.scalars[:] = 0.0
@@ -90,19 +97,45 @@ def test_two_rank_gloo_matches_single_process(tmp_path, world):
         assert np.array_equal(got, rb[name]), name
 
 
-def test_sharded_path_refuses_find_melt_using_spread_mass():
-    """grd%spread_mass_old would have to be summed over the ranks as well: the sharded path says so instead of computing
-    a melt flux from a partial sum"""
-    import numpy as np
-    import pytest
+@pytest.mark.parametrize("variant", [1, 2])
+def test_two_rank_find_melt_using_spread_mass(tmp_path, variant):
+    """find_melt_using_spread_mass in the sharded path (IB:5490-5503, 3436-3445): grd%spread_mass_old (variant 2: with
+    Iceberg_melt_without_decay also spread_mass_tmp, IB:3411-3413) is summed over the ranks with the accumulator planes; the
+    melt flux every rank ends with is the single-process one"""
+    import oracle_lib
+    import parity as P
+    from icebergs_amd import synthetic as S, types as T
+    oracle_lib.build()
+    nbergs, nsteps, world = 5000, 3, 2
+    port = 31500 + (os.getpid() % 2000) + variant
+    mp.spawn(_worker, args=(world, port, nbergs, nsteps, str(tmp_path), variant), nprocs=world, join=True)
+    grid, p, b = S.config_c2(n=nbergs, seed=17, continents=True)
+    p.find_melt_using_spread_mass = 1
+    p.Iceberg_melt_without_decay = 1 if variant == 2 else 0
+    rb, racc, rout, rscal = P.run_oracle(grid, p, b, nsteps)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    fm = T.ACC_NAMES["floating_melt"]
+    assert np.abs(racc[fm]).max() > 0
+    for r in range(world):
+        assert P.rel_err(parts[r]["acc"][fm], racc[fm]) <= P.TOL_GRID, r
+        for k in range(T.NOUT):
+            assert P.rel_err(parts[r]["out"][k], rout[k]) <= P.TOL_GRID, (r, k)
+    for name in P.TRAJ_FIELDS + P.SIZE_FIELDS:
+        got = np.concatenate([parts[r]["b_" + name] for r in range(world)])
+        assert np.array_equal(got, rb[name]), name
+
+
+def test_sharded_find_melt_needs_its_planes():
+    """find_melt_using_spread_mass in the sharded path reduces two more planes: the stepper refuses to run without them"""
     from icebergs_amd import synthetic as S
-    from icebergs_amd.distributed import accumulator_views
+    from icebergs_amd.distributed import ShardedStepper, accumulator_views
     from icebergs_amd import types as T
     p = S.default_params()
     p.find_melt_using_spread_mass = 1
-    block = np.zeros(T.NACC * 16 + T.NSCALAR)
-    with pytest.raises(NotImplementedError):
-        accumulator_views(block, 16, 0, p)
-    p.find_melt_using_spread_mass = 0
+    block = torch.zeros(T.NACC * 16 + T.NSCALAR, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        ShardedStepper(None, block, 16, 0, None, params=p)
+    st = ShardedStepper(None, block, 16, 0, None, params=p, spread_mass_old=torch.zeros(32, dtype=torch.float64))
+    assert st.spread_mass_old is not None
     planes, scalars = accumulator_views(block, 16, 0, p)
-    assert scalars.size == T.NSCALAR and planes.size % 16 == 0
+    assert scalars.numel() == T.NSCALAR and planes.numel() % 16 == 0

@@ -432,6 +432,51 @@ def test_find_melt_using_spread_mass(oracle, variant):
     assert np.abs(ref[1][k]).max() > 0 and not np.allclose(ref[1][k], plain[1][k], rtol=1e-3)   # it IS a different flux
 
 
+@pytest.mark.parametrize("without_decay", [False, True])
+def test_find_melt_using_spread_mass_sharded_stepper(oracle, without_decay):
+    """the sharded path with find_melt_using_spread_mass: the two planes of grd%spread_mass_old / spread_mass_tmp live in the
+    caller's tensor (kid_bind_spread_mass_old) where the ranks sum them between the local work and the gather; two shards on
+    one GPU, summed by hand the way the all-reduce would, give the single-handle result"""
+    import torch
+    from icebergs_amd import types as T, distributed as D
+    from icebergs_amd.framework import Icebergs
+    grid, p, b = S.config_c2(n=6000, seed=35, continents=True)
+    p.find_melt_using_spread_mass = 1
+    p.Iceberg_melt_without_decay = 1 if without_decay else 0
+    ref = P.run_hip(grid, p, b, 3)
+    shards = [D.take_shard(b, r, 2) for r in range(2)]
+    hs, accs, olds = [], [], []
+    try:
+        for sh in shards:
+            ib = Icebergs(grid, p, capacity=len(sh["lon"]))
+            ib.upload_bergs(sh)
+            ib.set_resort_interval(0)
+            _, count = ib.accum_device_ptr()
+            acc = torch.zeros(count, dtype=torch.float64, device="cuda")
+            old = torch.zeros(2 * ib.ncell, dtype=torch.float64, device="cuda")
+            ib.bind_accum_buffer(acc.data_ptr(), count)
+            ib.bind_spread_mass_old(old.data_ptr(), old.numel())
+            hs.append(ib); accs.append(acc); olds.append(old)
+        for step in range(3):
+            for ib in hs:
+                ib.step_local()
+                ib.sync()
+            tot_acc, tot_old = accs[0] + accs[1], olds[0] + olds[1]          # what the all-reduce leaves on every rank
+            for ib, acc, old in zip(hs, accs, olds):
+                acc.copy_(tot_acc); old.copy_(tot_old)
+                torch.cuda.synchronize()
+                ib.step_gather()
+                ib.sync()
+        acc0, out0, _ = hs[0].fetch()
+        k = T.ENUMS["KID_A_FLOATING_MELT"]
+        assert np.abs(ref[1][k]).max() > 0
+        assert P.rel_err(acc0[k], ref[1][k]) <= P.TOL_GRID
+        assert P.rel_err(out0[T.OUT_NAMES["spread_mass"]], ref[2][T.OUT_NAMES["spread_mass"]]) <= P.TOL_GRID
+    finally:
+        for ib in hs:
+            ib.close()
+
+
 @pytest.mark.parametrize("verlet", [False, True])
 def test_periodic_reentry(oracle, verlet):
     """periodic_reentry=1 on the zonally cyclic config-2 grid: bergs driven across the seam in both directions come back on

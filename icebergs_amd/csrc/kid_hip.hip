@@ -224,6 +224,18 @@ __global__ void __launch_bounds__(256) compact_i64_kernel(const int64_t *src, in
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
   if (k < n && alive[k]) dst[pos[k]] = src[k];
 }
+// Rows that must survive a dead-tail drop, a compaction or a re-binning.  In a domain-decomposed run (kid_migrate.inc) a berg
+// that left the tile is a DEAD row whose cell lies outside the computational domain until kid_pack_emigrants has collected
+// it (evolve -> move_berg_between_cells -> send_bergs_to_other_pes is the reference's own order, IB:5433-5447); it counts as
+// occupied here, keeps its cell as sort key and is never stepped (alive = 0).  Once packed, its cell is moved inside.
+struct KeepSel { int isc, iec, jsc, jec; const double *halo; };
+__global__ void __launch_bounds__(256) keep_flags_kernel(const int32_t *alive, const int32_t *ine, const int32_t *jne, const KeepSel s, int32_t *keep, long long n) {
+  const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
+  if (k >= n) return;
+  const int i = ine[k], j = jne[k];
+  const bool waiting = (i < s.isc || i > s.iec || j < s.jsc || j > s.jec) && !(s.halo && s.halo[k] >= 0.5);   // the selection of FW:3027-3035, 3101-3109
+  keep[k] = (alive[k] != 0 || waiting) ? 1 : 0;
+}
 __global__ void __launch_bounds__(256) alive_to_u32_kernel(const int32_t *alive, unsigned *flag, long long n) {
   const long long k = (long long)blockIdx.x * 256ll + threadIdx.x;
   if (k < n) flag[k] = alive[k] ? 1u : 0u;
@@ -331,6 +343,9 @@ struct kid_handle {
   int redo_parity = 0; bool redo_prezeroed = false, acc_prezeroed = false;
   bool uploaded_nonzero[KID_NB_F64] = {};  // fields that held anything but zeros at the last upload
   bool tail_valid = false;                 // the dead rows are exactly the tail (true between a re-binning and the next launch)
+  bool mig_mode = false;                   // the host exchanges bergs with other handles (kid_migrate.inc): dead rows waiting to be packed are kept
+  int32_t *d_keep = nullptr;               // layout flags of such a run (keep_flags_kernel)
+  long long mig_last[2] = {0, 0};          // records of the last pack call per slot: sizes the pinned staging buffer
   bool env_ever_stored = false;            // some launch since the last upload wrote berg%uo..od
   double *d_orient = nullptr;              // bond-derived hexagon orientation per berg (mts / interacting bergs)
   hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
@@ -545,6 +560,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_trc) (void)hipFree(h->d_trc);
   if (h->d_geo) (void)hipFree(h->d_geo);
   if (h->d_hotok) (void)hipFree(h->d_hotok);
+  if (h->d_keep) (void)hipFree(h->d_keep);
   if (h->d_acc_own) (void)hipFree(h->d_acc_own);
   if (h->d_out) (void)hipFree(h->d_out);
   if (h->d_totals) (void)hipFree(h->d_totals);
@@ -841,6 +857,19 @@ int kid_download_bergs(kid_handle *h, kid_berg_soa *host) {
   return KID_OK;
 }
 
+// which rows are occupied, for tail drops, compaction and re-binning: `alive`, plus (decomposed runs) the rows still waiting
+// to be packed for a neighbour
+static int layout_flags(kid_handle *h, const int32_t **flags) {
+  *flags = h->bp.i[KID_BI_ALIVE];
+  if (!h->mig_mode || h->n == 0) return KID_OK;
+  if (!h->d_keep) KID_HIP(h, hipMalloc(&h->d_keep, (size_t)h->capacity * sizeof(int32_t)));
+  const KeepSel ks{h->gd.isc, h->gd.iec, h->gd.jsc, h->gd.jec, h->flags.has_static ? h->bp.f[KID_B_HALO_BERG] : nullptr};
+  hipLaunchKernelGGL(keep_flags_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], ks, h->d_keep, (long long)h->n);
+  KID_HIP(h, hipGetLastError());
+  *flags = h->d_keep;
+  return KID_OK;
+}
+
 int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
@@ -853,6 +882,14 @@ int kid_num_bergs(kid_handle *h, int64_t *n_slots, int64_t *n_alive) {
     KID_HIP(h, hipMemcpyAsync(&cnt, h->d_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
     KID_HIP(h, hipStreamSynchronize(h->stream));
     *n_alive = (int64_t)cnt;
+    if (h->tail_valid && h->mig_mode && (int64_t)cnt < h->n) {   // decomposed run: the tail is what is neither alive nor waiting to be packed
+      const int32_t *flags = nullptr;
+      { const int rc = layout_flags(h, &flags); if (rc) return rc; }
+      KID_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(cnt), h->stream));
+      hipLaunchKernelGGL(count_alive_kernel, dim3((unsigned)std::min<long long>((h->n + 255) / 256, 1024)), dim3(256), 0, h->stream, flags, (long long)h->n, h->d_count);
+      KID_HIP(h, hipMemcpyAsync(&cnt, h->d_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+      KID_HIP(h, hipStreamSynchronize(h->stream));
+    }
     if (h->tail_valid && (int64_t)cnt < h->n) {  // a re-binning left the dead at the tail: drop them now that the count is known
       h->n = (int64_t)cnt;
       if (n_slots) *n_slots = h->n;
@@ -877,28 +914,38 @@ int kid_compact_bergs(kid_handle *h) {
     h->scan_tmp_bytes = tmp;
     KID_HIP(h, hipMalloc(&h->d_scan_tmp, tmp));
   }
-  hipLaunchKernelGGL(alive_to_u32_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], h->d_flag, n);
+  const int32_t *live = nullptr;   // alive, or alive + waiting to be packed (decomposed runs)
+  { const int rc_l = layout_flags(h, &live); if (rc_l) return rc_l; }
+  hipLaunchKernelGGL(alive_to_u32_kernel, dim3(nb), dim3(256), 0, h->stream, live, h->d_flag, n);
   size_t tmp = h->scan_tmp_bytes;
   KID_HIP(h, rocprim::exclusive_scan(h->d_scan_tmp, tmp, h->d_flag, h->d_pos, 0u, (size_t)n, rocprim::plus<unsigned>(), h->stream));
   int64_t n_alive = 0;
-  int rc = kid_num_bergs(h, nullptr, &n_alive);
-  if (rc) return rc;
+  // (the count of rows that stay)
+  {
+    unsigned long long cnt = 0;
+    KID_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(cnt), h->stream));
+    hipLaunchKernelGGL(count_alive_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, h->stream, live, n, h->d_count);
+    KID_HIP(h, hipMemcpyAsync(&cnt, h->d_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+    KID_HIP(h, hipStreamSynchronize(h->stream));
+    n_alive = (int64_t)cnt;   // rows that stay
+  }
   for (int f = 0; f < KID_NB_F64; ++f) {
-    hipLaunchKernelGGL(compact_f64_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.f[f], h->d_spare_f64, h->bp.i[KID_BI_ALIVE], h->d_pos, n);
+    hipLaunchKernelGGL(compact_f64_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.f[f], h->d_spare_f64, live, h->d_pos, n);
     std::swap(h->bp.f[f], h->d_spare_f64);
   }
   {
     int64_t *spare = (int64_t *)h->d_spare_f64;  // same element size
-    hipLaunchKernelGGL(compact_i64_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.id, spare, h->bp.i[KID_BI_ALIVE], h->d_pos, n);
+    hipLaunchKernelGGL(compact_i64_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.id, spare, live, h->d_pos, n);
     double *old = (double *)h->bp.id; h->bp.id = spare; h->d_spare_f64 = old;
   }
+  const bool keeps_dead = (live != h->bp.i[KID_BI_ALIVE]);   // rows waiting to be packed stay dead: their flag moves with them
   for (int f = 0; f < KID_NB_I32; ++f) {
-    if (f == KID_BI_ALIVE) continue;
+    if (f == KID_BI_ALIVE && !keeps_dead) continue;
     int32_t *spare = (int32_t *)h->d_flag;  // reuse the flag buffer as int32 spare
-    hipLaunchKernelGGL(compact_i32_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[f], spare, h->bp.i[KID_BI_ALIVE], h->d_pos, n);
+    hipLaunchKernelGGL(compact_i32_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[f], spare, live, h->d_pos, n);
     unsigned *old = (unsigned *)h->bp.i[f]; h->bp.i[f] = spare; h->d_flag = old;
   }
-  if (n_alive > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n_alive + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], 1, (long long)n_alive);
+  if (!keeps_dead && n_alive > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n_alive + 255) / 256)), dim3(256), 0, h->stream, h->bp.i[KID_BI_ALIVE], 1, (long long)n_alive);
   KID_HIP(h, hipGetLastError());
   KID_HIP(h, hipStreamSynchronize(h->stream));
   h->n = n_alive;
@@ -976,17 +1023,19 @@ static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_
     for (int f = 0; f < KID_NB_I32; ++f) KID_HIP(h, hipMalloc(&h->bp_alt.i[f], (size_t)h->capacity * sizeof(int32_t)));
     KID_HIP(h, hipMalloc(&h->bp_alt.id, (size_t)h->capacity * sizeof(int64_t)));
   }
+  const int32_t *live = nullptr;   // alive, or alive + waiting to be packed (decomposed runs): those keep their cell as key
+  { const int rc_l = layout_flags(h, &live); if (rc_l) return rc_l; }
   const unsigned *perm = nullptr;
   if (h->stable_resort) {
     unsigned bits = 1; while ((1ull << bits) <= (unsigned long long)dead_key) ++bits;
-    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], h->bp.i[KID_BI_ALIVE],
+    hipLaunchKernelGGL(cell_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], live,
                        h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_idx[0], n);
     size_t tmp = h->sort_tmp_bytes;
     KID_HIP(h, rocprim::radix_sort_pairs(h->d_sort_tmp, tmp, h->d_key[0], h->d_key[1], h->d_idx[0], h->d_idx[1], (size_t)n, 0u, bits, h->stream));
     perm = h->d_idx[1];
   } else {
     KID_HIP(h, hipMemsetAsync(h->d_cell_hist, 0, ((size_t)h->ncell + 1) * sizeof(unsigned), h->stream));
-    hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], h->bp.i[KID_BI_ALIVE],
+    hipLaunchKernelGGL(cell_rank_kernel, dim3(nb), dim3(256), 0, h->stream, h->bp.i[KID_BI_INE], h->bp.i[KID_BI_JNE], live,
                        h->gd.isd, h->gd.jsd, h->ni, dead_key, h->d_key[0], h->d_key[1], h->d_cell_hist, n);
     size_t tmp = h->cscan_tmp_bytes;
     KID_HIP(h, rocprim::exclusive_scan(h->d_cscan_tmp, tmp, h->d_cell_hist, h->d_cell_hist, 0u, (size_t)h->ncell + 1, rocprim::plus<unsigned>(), h->stream));

@@ -183,6 +183,13 @@ int kid_write_bond_trajectories(kid_handle *h, const char *path);
  * KID_ECAPACITY is returned.  kid_unpack_immigrants appends, resets the *_old fields (FW:3573-3577), finds each berg's cell on
  * this grid (check_and_find_cell FW:5973-6008) and its xi / yj (FW:3634); a berg no cell of the data domain takes is dropped
  * and KID_EINVAL returned (the reference's FATAL, FW:3660).  Bonds, mts and dem: KID_EUNSUPPORTED. */
+/* A decomposed host calls kid_buffer_width once at initialisation (ice_bergs_framework_init sizes its buffers there,
+ * FW:1263-1292).  From the first migration call on the handle is in "decomposed" mode: a berg that left the tile is a dead row
+ * whose cell lies outside the computational domain until a pack call has collected it, and such rows survive whatever the host
+ * does between kid_evolve_icebergs and the exchange -- kid_move_berg_between_cells (the reference's own order, IB:5437-5447),
+ * the dead-tail drop of kid_num_bergs, kid_compact_bergs; the rows of bergs already packed are reclaimed by those calls, and
+ * by kid_unpack_immigrants itself before it reports KID_ECAPACITY.  A handle that never makes a migration call deletes leavers
+ * at once, as a PE without neighbours does (FW:3024-3041). */
 int kid_buffer_width(kid_handle *h, int32_t *width);
 int kid_pack_emigrants(kid_handle *h, int32_t dir, double *buf, int64_t capacity, int64_t *n);
 int kid_unpack_immigrants(kid_handle *h, const double *buf, int64_t n);

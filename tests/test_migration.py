@@ -29,8 +29,11 @@ def _grid(tx, ty, ntx, nty):
     return g
 
 
-def _phases(ibs, exchange):
-    """one step of icebergs_run over all handles, phase by phase (IB:5125-5512), the exchange after evolve_icebergs"""
+def _phases(ibs, exchange, rebin=False):
+    """one step of icebergs_run over all handles, phase by phase (IB:5125-5512), the exchange after evolve_icebergs.
+    rebin: the reference's own order -- evolve_icebergs, move_berg_between_cells (IB:5437), then send_bergs_to_other_pes
+    (IB:5447) -- with a count query in between: the bergs waiting to be packed are dead rows at that point and must
+    survive the re-binning, the dead-tail drop of kid_num_bergs and the compaction"""
     def call(ib, name):
         ib._check(getattr(ib.lib, name)(ib.h), name)
     p = next(iter(ibs.values())).params
@@ -39,6 +42,11 @@ def _phases(ibs, exchange):
         if not p.old_interp_flds_order:
             call(ib, "kid_interp_gridded_fields_to_bergs")
         call(ib, "kid_evolve_icebergs")
+        if rebin:
+            ib.move_berg_between_cells()
+            ib.num_bergs()
+            if rebin == "compact":
+                ib.compact()
     sent = exchange(ibs)
     for ib in ibs.values():
         if not p.old_interp_flds_order:
@@ -70,8 +78,8 @@ def _exchange(ntx, nty, pair=False):
     return run
 
 
-@pytest.mark.parametrize("old_order,pair", [(1, False), (0, False), (1, True)])
-def test_two_by_two_tiles_match_the_undivided_grid(old_order, pair):
+@pytest.mark.parametrize("old_order,pair,rebin", [(1, False, False), (0, False, False), (1, True, False), (1, True, True), (1, False, "compact")])
+def test_two_by_two_tiles_match_the_undivided_grid(old_order, pair, rebin):
     from icebergs_amd.framework import Icebergs
     ntx = nty = 2
     whole = _grid(None, None, ntx, nty)
@@ -81,6 +89,9 @@ def test_two_by_two_tiles_match_the_undivided_grid(old_order, pair):
     b = S.place_bergs(whole, n, 11, (2, NI * ntx - 1), (2, NJ * nty - 1))
     ref = Icebergs(whole, p, capacity=n)
     ref.upload_bergs(b)
+    # with re-binning / compaction between evolve and the exchange, a tile has room for little more than its own share:
+    # the rows of the bergs that left must be reclaimed (> 500 arrivals per tile over the run, ~1500 residents)
+    tile_cap = n if not rebin else 2300
     tiles = {}
     for tx in range(ntx):
         for ty in range(nty):
@@ -89,14 +100,15 @@ def test_two_by_two_tiles_match_the_undivided_grid(old_order, pair):
             bt = {k: (v[sel].copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()}
             bt["ine"] = bt["ine"] - tx * NI
             bt["jne"] = bt["jne"] - ty * NJ
-            ib = Icebergs(g, p, capacity=n)
+            ib = Icebergs(g, p, capacity=tile_cap)
+            assert ib.buffer_width() == 34          # the decomposed host's first call (ice_bergs_framework_init, FW:1263): decomposed mode from here on
             ib.upload_bergs(bt)
             tiles[(tx, ty)] = ib
     assert ref.buffer_width() == 34
     moved = 0
     for _ in range(40):
         _phases({"whole": ref}, lambda ibs: 0)
-        moved += _phases(tiles, _exchange(ntx, nty, pair))
+        moved += _phases(tiles, _exchange(ntx, nty, pair), rebin)
     assert moved > 500, moved                                   # bergs did cross tile boundaries, corners included
     rb = ref.download_bergs()
     ra = rb["alive"] != 0

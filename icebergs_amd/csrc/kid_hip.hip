@@ -371,6 +371,7 @@ struct kid_handle {
   hipGraphExec_t sub_graph_exec = nullptr;  // the captured sub-step loop of evolve_icebergs_mts
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
   bool use_graph = true;
+  int fused_blocks = 0;                     // co-resident workgroups of mts_substeps_kernel (0: not asked yet)
   Flags flags{0, 0, 1, 0, 0};
   // trajectories (kid_traj.inc): one buffer per sampled field, grown on demand
   bool traj_on = false; kid_traj_params traj_params{}; double *d_traj_f[64] = {}; double *d_traj_day = nullptr; int64_t *d_traj_id = nullptr;

@@ -367,6 +367,9 @@ struct kid_handle {
   int mb = 0; bool mts_ready = false, mts_dirty = true, have_bonds = false, visited = false;
   unsigned long long *d_key64[2] = {nullptr, nullptr}; int *d_rows[2] = {nullptr, nullptr};
   int *d_static_rows = nullptr; long long static_rows_n = -1, static_rows_cap = 0;   // rows ordered by the five static `inorder` keys (mts_build_order)
+  unsigned long long *d_last_key = nullptr; int *d_order_flag = nullptr; long long order_n = -1;   // cell key of every row at the last sort: an unchanged population keeps its order
+  MtsDev mts_shadow{}; bool mts_shadow_valid = false;   // what d_mts holds (the table is re-uploaded only when it differs)
+  int conglom_batch = 8;                                // label-propagation sweeps launched before the first convergence check (set_conglom_ids)
   void *d_mts_tmp = nullptr; size_t mts_tmp_bytes = 0;
   hipGraphExec_t sub_graph_exec = nullptr;  // the captured sub-step loop of evolve_icebergs_mts
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
@@ -904,6 +907,7 @@ int kid_compact_bergs(kid_handle *h) {
   KID_HIP(h, hipSetDevice(h->device));
   { const int rc_j = lanes_drain(h); if (rc_j) return rc_j; }
   if (h->n == 0) return KID_OK;
+  h->static_rows_n = -1;   // rows move: the cached traversal order (mts_build_order) is of the old rows
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (!h->d_spare_f64) {
@@ -1002,6 +1006,7 @@ int kid_move_berg_between_cells(kid_handle *h) {
 }
 // with_lane: the lane array moves with the rows and `list` (row numbers, *list_count of them) is translated
 static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_count) {
+  h->static_rows_n = -1;   // rows move: the cached traversal order (mts_build_order) is of the old rows
   const long long n = h->n;
   const unsigned nb = (unsigned)((n + 255) / 256);
   const unsigned dead_key = (unsigned)h->ncell;  // larger than any cell index

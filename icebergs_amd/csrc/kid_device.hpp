@@ -16,7 +16,7 @@ namespace kid {
 // Measurement-only macros (KID_EXP_*) change what the library computes or how it is laid out; they are honoured only
 // together with -DKID_EXPERIMENTS, which kid_version() reports, so that a stray -D cannot ship wrong answers silently.
 #if !defined(KID_EXPERIMENTS) && (defined(KID_EXP_MARKERS) || defined(KID_EXP_NO_ATOMICS) || defined(KID_EXP_MAXRUN) || defined(KID_EXP_CHUNK) || defined(KID_EXP_NUM_VGPR) || \
-                                  defined(KID_EXP_MTS_NOPAIR) || defined(KID_EXP_MTS_NOBARRIER))
+                                  defined(KID_EXP_MTS_NOPAIR))
 #error "KID_EXP_* macros are measurement-only: build with -DKID_EXPERIMENTS to use them"
 #endif
 // Keeps the machine scheduler from interleaving two long phases (each wants ~100 VGPRs for its own loads in

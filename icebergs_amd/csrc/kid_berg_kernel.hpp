@@ -110,18 +110,21 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   // The hot build of the fused RK4 step parks what only the thermodynamics needs in its wave's staging rows (idle until
   // the first cell_add) instead of holding the registers -- or re-reading HBM -- across the RK4 loop.
   constexpr bool SCATTER_ = (PH & (PH_THERMO | PH_SPREAD)) != 0;
-  constexpr bool PARK = FAST && SCATTER_ && RK && (PH & PH_EVOLVE) != 0;
-  double park_ms = 0., park_bits = 0., park_hd = 0.;
+  constexpr bool PARK = FAST && SCATTER_ && (PH & PH_EVOLVE) != 0;
+  double park_ms = 0., park_bits = 0., park_hd = 0., park_flk = 0., park_flbits = 0., park_flbergy = 0.;
   if constexpr (PARK) {
     park_ms = ldg(b.f[KID_B_MASS_SCALING], kk); park_bits = ldg(b.f[KID_B_MASS_OF_BITS], kk);
     park_hd = (PH & PH_THERMO) ? ldg(b.f[KID_B_HEAT_DENSITY], kk) : 0.;
+    if (Fl<K>::has_fl(fl)) {
+      park_flk = ldg(b.f[KID_B_FL_K], kk); park_flbits = ldg(b.f[KID_B_MASS_OF_FL_BITS], kk); park_flbergy = ldg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk);
+    }
   }
   bool was_alive = inrange && (alive_v != 0);
   if (FAST && redo.lane) { if (was_alive && lane_v >= redo.step) was_alive = false; }
   if (__ballot(was_alive) == 0ull) {  // wave-uniform; every other lane stays to the end (wave-level sums below)
     keep(d.ine); keep(d.jne); keep(d.xi); keep(d.yj); keep(d.lon); keep(d.lat); keep(d.uvel); keep(d.vvel); keep(d.axn); keep(d.ayn);
     keep(d.bxn); keep(d.byn); keep(t.M); keep(t.T); keep(t.W); keep(t.L); keep(t.n_bonds); keep(t.static_berg);
-    keep(park_ms); keep(park_bits); keep(park_hd);
+    keep(park_ms); keep(park_bits); keep(park_hd); keep(park_flk); keep(park_flbits); keep(park_flbergy);
     continue;
   }
   double *scal = acc + (size_t)KID_NACC * ncell;
@@ -161,6 +164,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     lds_double *row = seg.val + (int)__lane_id();
     row[0 * KID_ROW] = t.M; row[1 * KID_ROW] = t.T; row[2 * KID_ROW] = t.W; row[3 * KID_ROW] = t.L;
     row[4 * KID_ROW] = park_ms; row[5 * KID_ROW] = park_bits; row[6 * KID_ROW] = park_hd;
+    if (Fl<K>::has_fl(fl)) { row[7 * KID_ROW] = park_flk; row[8 * KID_ROW] = park_flbits; row[9 * KID_ROW] = park_flbergy; }
   }
   Env e = {};
   unsigned tickets = 0u;
@@ -190,6 +194,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
         const lds_double *row = seg.val + (int)__lane_id();
         t.M = row[0 * KID_ROW]; t.T = row[1 * KID_ROW]; t.W = row[2 * KID_ROW]; t.L = row[3 * KID_ROW];
         park_ms = row[4 * KID_ROW]; park_bits = row[5 * KID_ROW]; park_hd = row[6 * KID_ROW];
+        if (Fl<K>::has_fl(fl)) { park_flk = row[7 * KID_ROW]; park_flbits = row[8 * KID_ROW]; park_flbergy = row[9 * KID_ROW]; }
       }
       if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
         const int slot = atomicAdd(redo.count, 1);
@@ -237,12 +242,19 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
 
   if (PH & PH_FL) {  // footloose_calving (IB:5453, 2503-2734) on the berg's own rows between its evolve and its thermodynamics:
     // per berg the reference's order is evolve -> footloose -> thermodynamics too, and nothing of another berg is read.
-    // The state goes through memory (this lane has just stored it); children are appended behind the population and get
-    // their thermodynamics + spreading from a second launch over the new rows (kid_step_local).
+    // Children are appended behind the population and get their thermodynamics + spreading from a second launch over the
+    // new rows (kid_step_local).  The hot build of the fused step keeps the berg in registers across the phase (PARK: its
+    // mass_scaling, fl_k and bits were fetched with everything else at the top); elsewhere the state goes through the row.
     if (was_alive && !skipped && t.alive) {
       const FlChildCtx cx{redo.fl_cursor, redo.fl_counter, n, redo.fl_capacity, redo.fl_iNg, redo.fl_step};
-      footloose_one(g, p, b, cx, kk, acc, ncell, scal);
-      t.M = ldg(b.f[KID_B_MASS], kk); t.T = ldg(b.f[KID_B_THICKNESS], kk); t.W = ldg(b.f[KID_B_WIDTH], kk); t.L = ldg(b.f[KID_B_LENGTH], kk);
+      if constexpr (PARK) {
+        bool touched = false;
+        footloose_core(g, p, b, cx, kk, d.ine, d.jne, CellOf<FAST>::make(g, pk, d.ine, d.jne).area(), park_ms, t.static_berg, t.M, t.T, t.W, t.L, park_flk, park_flbits, touched, acc, ncell, scal);
+        if (touched) { park_flbits = ldg(b.f[KID_B_MASS_OF_FL_BITS], kk); park_flbergy = ldg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk); }
+      } else {
+        footloose_one(g, p, b, cx, kk, acc, ncell, scal);
+        t.M = ldg(b.f[KID_B_MASS], kk); t.T = ldg(b.f[KID_B_THICKNESS], kk); t.W = ldg(b.f[KID_B_WIDTH], kk); t.L = ldg(b.f[KID_B_LENGTH], kk);
+      }
     }
   }
 
@@ -256,7 +268,8 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       t.mass_of_bits = ldg(b.f[KID_B_MASS_OF_BITS], kk);
       t.heat_density = (PH & PH_THERMO) ? ldg(b.f[KID_B_HEAT_DENSITY], kk) : 0.;
     }
-    if (Fl<K>::has_fl(fl)) {
+    if (PARK && Fl<K>::has_fl(fl)) { t.mass_of_fl_bits = park_flbits; t.mass_of_fl_bergy_bits = park_flbergy; t.fl_k = park_flk; }
+    else if (Fl<K>::has_fl(fl)) {
       t.mass_of_fl_bits = ldg(b.f[KID_B_MASS_OF_FL_BITS], kk); t.mass_of_fl_bergy_bits = ldg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk);
       t.fl_k = ldg(b.f[KID_B_FL_K], kk);
     } else { t.mass_of_fl_bits = 0.; t.mass_of_fl_bergy_bits = 0.; t.fl_k = 0.; }

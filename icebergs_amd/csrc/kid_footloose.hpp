@@ -153,23 +153,24 @@ __device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, 
   return true;
 }
 
+// footloose_calving for one berg (IB:2503-2734).  The berg's own values come in and go out through the arguments (the fused
+// step holds them in registers: no round trip through memory between its evolve and its thermodynamics); whatever
+// changes is ALSO written to the berg's row where the reference changes it, because calve_child reads the parent's row.
+// bits_rows_touched: calve_child(from_bits) has rewritten mass_of_fl_bits and mass_of_fl_bergy_bits of the row.
 template <class BP>
-__device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long q,
-                                              double *acc, size_t ncell, double *scal) {
-  const int i = b.i[KID_BI_INE][q], j = b.i[KID_BI_JNE][q];
+__device__ __forceinline__ void footloose_core(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long q, int i, int j, double area,
+                                               double ms, double static_berg, double &M, double &T, double &W, double &L, double &flk, double &bits,
+                                               bool &bits_rows_touched, double *acc, size_t ncell, double *scal) {
   if (i < g.isc || i > g.iec || j < g.jsc || j > g.jec) return;  // computational domain only, IB:2554
   const int c = g.idx(i, j);
-  const double area = g.geo[c].area, ms = b.f[KID_B_MASS_SCALING][q];
   // constants IB:2538-2547
   const double e1 = g.fl_e1, drho = RHO_SEAWATER - p.rho_bergs, sigmay = p.fl_strength * 1000;  // exp(pi/4) from the host
   const double lfootparam = e1 * RHO_SEAWATER * sigmay / (6 * p.rho_bergs * GRAVITY * drho);
   const double l_c = p.pi / (2. * sqrt(2.)), lw_c = FL_LW_C, B_c = p.fl_youngs / (12. * (1. - 0.3 * 0.3));
-  double T = b.f[KID_B_THICKNESS][q];
   const double l_w = kid_root4(lw_c * B_c * kid_cube(T));
   const double l_b = l_c * l_w;
   double nerr = 0., ncalved = 0.;
-  if (!(b.f[KID_B_STATIC_BERG][q] == 1 || b.f[KID_B_FL_K][q] < 0)) {
-    const double W = b.f[KID_B_WIDTH][q], L = b.f[KID_B_LENGTH][q];
+  if (!(static_berg == 1 || flk < 0)) {
     const double l_b3 = 3 * l_b;
     double cc = ceil((L - l_b3) / l_b3); const double Lmin = L - cc * l_b3;
     cc = ceil((W - l_b3) / l_b3); const double Wmin = W - cc * l_b3;
@@ -178,10 +179,9 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
     if (max_k != 0) {
       const double foot_l = lfootparam * T / l_w;
       const double foot_area = foot_l * l_b3;
-      const double flk = b.f[KID_B_FL_K][q];
       k = floor(flk / foot_area);
       if (k > max_k) k = max_k;
-      b.f[KID_B_FL_K][q] = flk - k * foot_area;
+      if (k != 0) { flk = flk - k * foot_area; b.f[KID_B_FL_K][q] = flk; }   // (k = 0 leaves fl_k as it is, bit for bit)
     }
     if (k > 0) {
       double ds, Ln, Wn;
@@ -199,26 +199,39 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
         ncalved += 1.;
       } else {
         const double dM_fl_bits = p.rho_bergs * T * dA;
-        b.f[KID_B_MASS_OF_FL_BITS][q] = b.f[KID_B_MASS_OF_FL_BITS][q] + dM_fl_bits;
+        bits = bits + dM_fl_bits;
+        b.f[KID_B_MASS_OF_FL_BITS][q] = bits;
         if (area != 0.) unsafeAtomicAdd(acc + (size_t)KID_A_FL_BITS_SRC * ncell + c, dM_fl_bits / (p.dt * area) * ms);
       }
       if (Ln <= 0 || Wn <= 0) nerr += 1.;  // FATAL IB:2649
       else {
         if (p.allow_bergs_to_roll) rolling(p, T, Wn, Ln);
+        W = Wn; L = Ln; M = Ln * Wn * T * p.rho_bergs;
         b.f[KID_B_THICKNESS][q] = T; b.f[KID_B_WIDTH][q] = Wn; b.f[KID_B_LENGTH][q] = Ln;
-        b.f[KID_B_MASS][q] = Ln * Wn * T * p.rho_bergs;
+        b.f[KID_B_MASS][q] = M;
       }
     }
   }
-  const double bits = b.f[KID_B_MASS_OF_FL_BITS][q];
   if (bits * ms > p.new_berg_from_fl_bits_mass_thres) {  // IB:2663-2673
     const double k = floor(bits * ms / p.new_berg_from_fl_bits_mass_thres);
     if (!calve_child(g, p, b, cx, q, k, l_b, true, 1u)) nerr += 1.;
+    bits_rows_touched = true;
     ncalved += 1.;
     if (area != 0.) unsafeAtomicAdd(acc + (size_t)KID_A_FL_BITS_SRC * ncell + c, -(k * p.new_berg_from_fl_bits_mass_thres / (p.dt * area)));
   }
   if (ncalved != 0.) unsafeAtomicAdd(scal + KID_S_NBERGS_CALVED_FL, ncalved);
   if (nerr != 0.) unsafeAtomicAdd(scal + KID_S_ERROR_COUNT, nerr);
+}
+// the berg's row as the only state (footloose_kernel, the general build)
+template <class BP>
+__device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long q,
+                                              double *acc, size_t ncell, double *scal) {
+  const int i = b.i[KID_BI_INE][q], j = b.i[KID_BI_JNE][q];
+  if (i < g.isc || i > g.iec || j < g.jsc || j > g.jec) return;
+  double M = b.f[KID_B_MASS][q], T = b.f[KID_B_THICKNESS][q], W = b.f[KID_B_WIDTH][q], L = b.f[KID_B_LENGTH][q];
+  double flk = b.f[KID_B_FL_K][q], bits = b.f[KID_B_MASS_OF_FL_BITS][q];
+  bool touched = false;
+  footloose_core(g, p, b, cx, q, i, j, g.geo[g.idx(i, j)].area, b.f[KID_B_MASS_SCALING][q], b.f[KID_B_STATIC_BERG][q], M, T, W, L, flk, bits, touched, acc, ncell, scal);
 }
 
 }  // namespace kid

@@ -465,7 +465,18 @@ static int check_params(kid_handle *h, const kid_params *p) {
 
 extern "C" {
 
-const char *kid_version(void) { return "kid_hip 0.1 (gfx950)"; }
+// The build's arithmetic and measurement switches are part of its identity: a library built with -DKID_EXPERIMENTS (KID_EXP_*
+// measurement macros, possibly wrong answers) or -DKID_EXACT_MATH (IEEE division/sqrt/pow everywhere) says so.
+const char *kid_version(void) {
+  return "kid_hip 0.2 (gfx950)"
+#ifdef KID_EXACT_MATH
+         " exact-math"
+#endif
+#ifdef KID_EXPERIMENTS
+         " EXPERIMENTS"
+#endif
+      ;
+}
 int64_t kid_sizeof(int which) {
   switch (which) { case 0: return (int64_t)sizeof(kid_params); case 1: return (int64_t)sizeof(kid_grid_desc);
                    case 2: return (int64_t)sizeof(kid_berg_soa); case 3: return (int64_t)sizeof(kid_bond_soa);

@@ -128,6 +128,33 @@ __device__ __forceinline__ double kid_powr(double x, double y) { return kid_pow(
 #else
 __device__ __noinline__ double kid_powr(double x, double y) { return (x == 0.) ? 0. : exp(y * log(x)); }
 #endif
+// The melt laws' x**0.8 and a / x**0.2 (IB:2912, 2914, 3046, 3084, 3100).  Both come from r = x**(-1/5): a single-precision seed
+// (v_log_f32, v_exp_f32: ~1e-6 relative) and three Newton steps r <- r + r (1 - x r^5) / 5 -- no division, the error goes
+// 1e-6 -> 3e-12 -> 3e-23 -- ~25 instructions against ~150 for exp(y log x) + a division; x**0.8 = x r.  Within ~1 ulp of pow.
+// Outside the seed's range (and for 0, inf, NaN) the general form; -DKID_EXACT_MATH keeps pow.
+#ifdef KID_EXACT_MATH
+__device__ __forceinline__ double kid_mul_rpow5(double a, double x) { return a / kid_pow(x, 0.2); }
+__device__ __forceinline__ double kid_pow08(double x) { return kid_pow(x, 0.8); }
+#else
+__device__ __noinline__ double kid_rpow5_slow(double x) { return 1. / kid_powr(x, 0.2); }
+__device__ __forceinline__ bool kid_rpow5_fast_range(double x) { return x > 1e-30 && x < 1e30; }
+__device__ __forceinline__ double kid_rpow5_newton(double x) {
+  double r = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const double r2 = r * r, r4 = r2 * r2;
+    const double e = __builtin_fma(-x, r4 * r, 1.0);
+    r = __builtin_fma(r, 0.2 * e, r);
+  }
+  return r;
+}
+__device__ __forceinline__ double kid_mul_rpow5(double a, double x) {
+  return a * (__builtin_expect(kid_rpow5_fast_range(x), 1) ? kid_rpow5_newton(x) : kid_rpow5_slow(x));
+}
+__device__ __forceinline__ double kid_pow08(double x) {
+  return __builtin_expect(kid_rpow5_fast_range(x), 1) ? x * kid_rpow5_newton(x) : kid_powr(x, 0.8);
+}
+#endif
 
 // ---- per-berg thermodynamic state -------------------------------------------------------------------------
 struct BergThermo {
@@ -175,10 +202,12 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
 #else
   const double Ss = 1.5 * kid_sqrt(dva) + 0.1 * dva;   // dva**0.5 (IB:2908)
 #endif
-  const double dvo08 = kid_powr(dvo, 0.8);
+  const double dvo08 = kid_pow08(dvo);
   double Mv = dmax(7.62e-3 * SST + 1.29e-3 * (SST * SST), 0.) * perday;
-  double Mb = dmax(0.58 * dvo08 * (SST + 4.0) * kid_rcp(kid_powr(L, 0.2)), 0.) * perday;
-  double Me = dmax(1. / 12. * (SST + 2.) * Ss * (1 + cos(p.pi * (IC * IC * IC))), 0.) * perday;
+  double Mb = dmax(kid_mul_rpow5(0.58 * dvo08 * (SST + 4.0), L), 0.) * perday;
+  // cos(pi IC^3): no lane of the wave in sea ice (IC = 0) is the common case, and cos(0) = 1 exactly
+  const double cos_ic = (__ballot(IC != 0.) == 0ull) ? 1.0 : cos(p.pi * (IC * IC * IC));
+  double Me = dmax(1. / 12. * (SST + 2.) * Ss * (1 + cos_ic), 0.) * perday;
   const bool has_fl = b.mass_of_fl_bits > 0.;
   const double Mv_fl = Mv, Me_fl = Me;  // IB:2924-2926
   const double N_max = Sw<K>::hexagonal_icebergs(p) ? 6.0 : 4.0;
@@ -237,7 +266,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   if (has_fl) {
     fl_bits_dimensions(p, T, Lfl, Wfl, Tfl);
     const double Mfl = b.mass_of_fl_bits, Volfl = Lfl * Wfl * Tfl;
-    const double Mb_fl = dmax(0.58 * dvo08 * (SST + 4.0) / kid_powr(Lfl, 0.2), 0.) * perday;
+    const double Mb_fl = dmax(kid_mul_rpow5(0.58 * dvo08 * (SST + 4.0), Lfl), 0.) * perday;
     Tnfl = dmax(Tfl - Mb_fl * dt, 0.);
     if (Sw<K>::use_operator_splitting(p)) {
       double nVolfl = Tnfl * Wfl * Lfl; const double Mnew1_fl = (nVolfl / Volfl) * Mfl; dMb_fl = Mfl - Mnew1_fl;
@@ -263,7 +292,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
     nMbits = Mbits + dMbitsE;
     const double Lbits = dmin(dmin(dmin(L, W), T), 40.);
     const double Abits = (Mbits / p.rho_bergs) / Lbits;
-    double Mbb = dmax(0.58 * dvo08 * (SST + 2.0) / kid_powr(Lbits, 0.2), 0.) * perday;
+    double Mbb = dmax(kid_mul_rpow5(0.58 * dvo08 * (SST + 2.0), Lbits), 0.) * perday;
     Mbb = p.rho_bergs * Abits * Mbb;
     dMbitsM = dmin(Mbb * dt, nMbits);
     nMbits = nMbits - dMbitsM;
@@ -274,7 +303,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
       nMbits_fl = Mbits_fl + dMbitsE_fl;
       const double Lbits_fl = dmin(dmin(dmin(Lfl, Wfl), Tfl), 40.);
       const double Abits_fl = (Mbits_fl / p.rho_bergs) / Lbits_fl;
-      double Mbb_fl = dmax(0.58 * dvo08 * (SST + 2.0) / kid_powr(Lbits_fl, 0.2), 0.) * perday;
+      double Mbb_fl = dmax(kid_mul_rpow5(0.58 * dvo08 * (SST + 2.0), Lbits_fl), 0.) * perday;
       Mbb_fl = p.rho_bergs * Abits_fl * Mbb_fl;
       dMbitsM_fl = dmin(Mbb_fl * dt, nMbits_fl);
       nMbits_fl = nMbits_fl - dMbitsM_fl;

@@ -31,6 +31,7 @@ def test_struct_layouts_match():
     assert lib.kid_sizeof(4) == C.sizeof(T.ForcingIn)
     assert lib.kid_sizeof(5) == C.sizeof(T.CalvingParams) and lib.kid_sizeof(6) == C.sizeof(T.CalvingIn)
     assert lib.kid_version().startswith(b"kid_hip")
+    assert b"EXPERIMENTS" not in lib.kid_version()   # the product library is not a measurement build (KID_EXP_* macros)
 
 
 def test_no_gpu_means_loud_failure():

@@ -551,6 +551,87 @@ def config_c4(nx=5, ny=11, hexagonal=True, radius=1500.0, thickness=200.0, ni=45
     return grid, p, b, bd
 
 
+def config_beam(kind="cantilever"):
+    """The reference's DEM beam tests (Wang 2020, sections 3.1 and 3.2; tests/dem_ssbeam_test, tests/dem_cbeam_test): the
+    generator's parameters (makeberg/makeberg.py main()) and the namelists (input.nml) restated.
+      cantilever: 3 rows of 30 square-packed elements 5 km apart (90, the '#=90' of input.nml:2,5), thickness 1 m, the first
+        element of every row static, the load 1.5e10/3 N on the last element of every row (dem_beam_test=2, IB:1870-1877);
+        dt = 100 s, 2000 sub-steps, dem_damping_coef 0.7.
+      supported:  one row of 29 elements 0.5 m apart ('#=29', input.nml:1), the two ends carry no vertical load and the
+        centre element is loaded with 1.5e5 N (dem_beam_test=1, IB:1862-1869); dt = 1 s, 1e5 sub-steps, damping 0.1.
+    Both: only_interactive_forces, dem_spring_coef 1e9 (Young's modulus), poisson 0.3, bonds from the radii (4 neighbours),
+    melt rates zero, a 20x20 grid of 15 km cells with the ocean at rest.  dem_tests_init (FW:4687-4710: start_lon = lon for
+    every berg, the west-most and east-most start_lon) is done here, on the host, as icebergs_init does it."""
+    gridres, ni, nj = 15000.0, 20, 20
+    grid = cartesian_grid(ni, nj, gridres, Lx=-1.0)
+    F = grid["forcing"]
+    F["sst"][:] = -1.0
+    F["sss"][:] = 34.0
+    p = default_params()
+    p.lat_ref, p.use_f_plane = 0.0, 0
+    p.Runge_not_Verlet, p.old_interp_flds_order, p.use_new_predictive_corrective = 0, 0, 1
+    p.old_bug_bilin, p.use_old_spreading = 0, 0
+    p.mts, p.dem, p.explicit_inner_mts = 1, 1, 1
+    p.iceberg_bonds_on, p.interactive_icebergs_on, p.internal_bergs_for_drag, p.only_interactive_forces = 1, 1, 1, 1
+    p.use_broken_bonds_for_substep_contact, p.break_bonds_on_sub_steps, p.short_step_mts_grounding = 0, 0, 0
+    p.constant_interaction_LW, p.force_convergence, p.convergence_tolerance = 0, 1, 1.0e-8
+    p.orig_dem_moment_of_inertia = 1
+    p.hexagonal_icebergs, p.max_bonds = 0, 4
+    p.poisson, p.dem_spring_coef = 0.3, 1.0e9
+    p.spring_coef = 1.0e-5
+    p.contact_distance, p.contact_spring_coef = 2000.0, 1.0e-8
+    p.contact_cells_lon = p.contact_cells_lat = 1
+    p.cdrag_grounding, p.h_to_init_grounding = 3.16e6, 200.0
+    p.fracture_criterion_stress, p.frac_thres_n, p.frac_thres_t = 0, 0.0, 0.0
+    p.radial_damping_coef = p.tangental_damping_coef = 0.0
+    p.scale_damping_by_pmag, p.critical_interaction_damping_on, p.tang_crit_int_damp_on = 0, 0, 0
+    p.use_updated_rolling_scheme, p.allow_bergs_to_roll = 0, 0
+    p.set_melt_rates_to_zero = 1
+    p.ustar_icebergs_bg, p.const_gamma = 0.0, 0
+    p.apply_thickness_cutoff_to_gridded_melt, p.apply_thickness_cutoff_to_bergs_melt, p.melt_cutoff = 1, 1, 10.0
+    xs0, ys0, h = 101.0e3, 151.0e3, 1.0
+    xs, ys, static = [], [], []
+    if kind == "cantilever":
+        r, rho, nrow, ncol = 2500.0, 900.0, 3, 30
+        p.dt, p.mts_sub_steps, p.dem_damping_coef, p.dem_beam_test = 100.0, 2000, 0.7, 2
+        for row in range(nrow):
+            for col in range(ncol):
+                xs.append(xs0 + 2 * r * col)
+                ys.append(ys0 + 2 * r * row)
+                static.append(1.0 if col == 0 else 0.0)
+    else:
+        r, rho, ncol = 0.25, 800.0, 29
+        p.dt, p.mts_sub_steps, p.dem_damping_coef, p.dem_beam_test = 1.0, 100000, 0.1, 1
+        for col in range(ncol):
+            xs.append(xs0 + 2 * r * col)
+            ys.append(ys0 + 2 * r)
+            static.append(0.0)
+    p.rho_bergs = rho
+    n = len(xs)
+    area = (2.0 * r) ** 2
+    b = empty_bergs(n)
+    b["lon"][:], b["lat"][:] = xs, ys
+    b["ine"][:] = np.floor(b["lon"] / gridres).astype(np.int32) + 1
+    b["jne"][:] = np.floor(b["lat"] / gridres).astype(np.int32) + 1
+    b["xi"][:] = b["lon"] / gridres - (b["ine"] - 1)
+    b["yj"][:] = b["lat"] / gridres - (b["jne"] - 1)
+    w = np.sqrt(area)
+    b["thickness"][:], b["width"][:], b["length"][:] = h, w, w
+    b["mass"][:] = h * rho * area
+    b["start_mass"][:] = b["mass"]
+    b["mass_scaling"][:] = 1.0
+    b["static_berg"][:] = static
+    b["lon_old"][:], b["lat_old"][:] = b["lon"], b["lat"]
+    b["start_lon"][:], b["start_lat"][:] = b["lon"], b["lat"]      # dem_tests_init
+    p.dem_tests_start_lon, p.dem_tests_end_lon = float(min(xs)), float(max(xs))
+    b["start_year"][:] = 1
+    b["start_day"][:] = 1.0e-6 * np.arange(n)
+    p.constant_length = p.constant_width = float(w)
+    b = sort_reference_order(b)
+    bd = bond_neighbours(b, n, 2.0 * r * 1.05, p.max_bonds)
+    return grid, p, b, bd
+
+
 def copy_bonds(bd):
     return {k: (v.copy() if hasattr(v, "copy") else v) for k, v in bd.items()}
 

@@ -283,6 +283,8 @@ typedef struct kid_params {
   double dem_spring_coef;         /* FW:804 */
   double dem_damping_coef;        /* FW:805 */
   double poisson;                 /* FW:803 */
+  double dem_tests_start_lon;     /* FW:595, 4707: start_lon of the west-most element (dem_tests_init; the host sets it, with every berg's start_lon = lon) */
+  double dem_tests_end_lon;       /* FW:596, 4707: ... of the east-most one */
   double frac_thres_n, frac_thres_t; /* FW:1355-1356 (already scaled by frac_thres_scaling) */
   /* switches (0/1) */
   int32_t Runge_not_Verlet;             /* FW:733 */
@@ -351,7 +353,8 @@ typedef struct kid_params {
   int32_t fl_init_child_xy_by_pe;       /* FW:606, 816: one random number for the whole run (old bug) instead of one per calving event */
   int32_t fl_rng_seed;                  /* seed of the counter-based generator that places footloose children (include/kid_rng.h); the
                                            reference seeds FMS's stream from (mpp_pe(), time), IB:2548 */
-  int32_t pad1;                         /* explicit: no implicit tail padding (Fortran stream I/O moves components) */
+  int32_t dem_beam_test;                /* FW:808: 1 = simply supported beam, 2 = cantilever beam (the loads of IB:1861-1877); 0 = off.
+                                           (An even number of int32 members: no implicit tail padding, Fortran stream I/O moves components) */
 } kid_params;
 
 #ifdef __cplusplus

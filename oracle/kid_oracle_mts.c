@@ -14,7 +14,7 @@
  * no halo bergs, so transfer_mts_bergs (FW:2136-2216) reduces to set_conglom_ids.  save_bond_forces=.true. (the
  * module default, FW:53): each bond pair is evaluated once per sub-step, by whichever of its two bergs comes first in
  * the traversal order (j outer, i inner, list order inside a cell), and mirrored to the other side.
- * Not restated: print_fracture, dem_beam_test, A68_test, skip_first_outer_mts_step, no_frac_first_ts (both one-shot
+ * Not restated: print_fracture, dem_beam_test = 3 (the angular-velocity test), A68_test, skip_first_outer_mts_step, no_frac_first_ts (both one-shot
  * module flags, default F), STS interactive bergs (the non-MTS second sweep of evolve_icebergs).
  * PARITY UNPINNED: the reference tree holds no recorded vector for this path that can be recomputed here (its DEM
  * regression numbers depend on netCDF restarts made by Python/netCDF4 tooling that is not in the image).
@@ -631,6 +631,15 @@ static void accel_explicit_inner_mts(mts_ctx *c, int64_t k, int i, int j, double
     }
   }
   if (p->dem) {
+    if (p->dem_beam_test > 0) {  /* IB:1861-1877: the loads of the beam tests of Wang (2020), sections 3.1 and 3.2 */
+      const double sl = BF(KID_B_START_LON, k);
+      if (p->dem_beam_test == 1) {        /* simply supported beam: no vertical load on the ends, a point load at the centre */
+        if (sl == p->dem_tests_start_lon || sl == p->dem_tests_end_lon) { D.F_y = 0.0; D.Fd_y = 0.0; }
+        else if (sl == 0.5 * (p->dem_tests_start_lon + p->dem_tests_end_lon)) D.F_y = D.F_y - 1.5e5;
+      } else if (p->dem_beam_test == 2) { /* cantilever beam: the load on the free end */
+        if (sl == p->dem_tests_end_lon) D.F_y = D.F_y - 1.5e10 / 3.;
+      }
+    }
     double M, R1;
     if (p->constant_interaction_LW) {
       M = p->constant_length * p->constant_width * BF(KID_B_THICKNESS, k) * p->rho_bergs;

@@ -100,6 +100,17 @@ __device__ __forceinline__ double kid_sqrt(double x) {
 }
 #endif
 
+// 1/sqrt(x), x > 0 finite: v_rsq_f64 (~23 bits) and two Newton steps y <- y + y (1 - x y^2) / 2, <= 1 ulp
+#ifndef KID_EXACT_MATH
+__device__ __forceinline__ double kid_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(y, 0.5 * e, y);
+  e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(y, 0.5 * e, y);
+}
+#endif
+
 // reference module constants, IB:68-80
 constexpr double RHO_ICE = 916.7, RHO_AIR = 1.1, RHO_SEAWATER = 1025.0, GRAVITY = 9.8;
 constexpr double CD_AV = 1.3, CD_AH = 0.0055, CD_WV = 0.9, CD_WH = 0.0012, CD_IV = 0.9;
@@ -537,8 +548,13 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
 #else
   double wave_rad = ap.wave_q * Cr * ampl * dmin(ampl, ap.F);
 #endif
+#ifdef KID_EXACT_MATH
   wmod = kid_sqrt(kid_fma(ua, ua, va * va));
   if (wmod != 0.) { const Rcp rw = kid_rcp(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
+#else
+  wmod = kid_fma(ua, ua, va * va);   // the unit vector of the wind: one Newton-refined reciprocal square root instead of a root and a reciprocal
+  if (wmod != 0.) { const double rw = kid_rsqrt(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
+#endif
   double c_ice = ap.c_ice;
   if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.;
   const double ex = -GRAVITY * e.ssh_x + wave_rad * uwave, ey = -GRAVITY * e.ssh_y + wave_rad * vwave;  // IB:2142-2149
@@ -578,9 +594,19 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
     RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va) - drag_ice * (v_star - vi) - drag_gnd * v_star;
     const double lambda = drag_ocn + drag_atm + drag_ice + drag_gnd;
     const double A11 = kid_fma(dt, lambda, 1.), A22 = A11;
-    const double detA = 1. * kid_rcp((A11 * A22) - (A12_0 * A21_0));
-    ax = detA * kid_fma(A22, RHS_x, -(A12_0 * RHS_y));
-    ay = detA * kid_fma(A11, RHS_y, -(A21_0 * RHS_x));
+#ifdef KID_EXACT_MATH
+    constexpr bool diagonal = false;
+#else
+    constexpr bool diagonal = RK;   // alpha = C_N = 0 (IB:2002-2013): A12 = A21 = 0 and A11 = A22, the 2x2 solve is a division by A11
+#endif
+    if constexpr (diagonal) {
+      const Rcp rA = kid_rcp(A11);
+      ax = RHS_x * rA; ay = RHS_y * rA;
+    } else {
+      const double detA = 1. * kid_rcp((A11 * A22) - (A12_0 * A21_0));
+      ax = detA * kid_fma(A22, RHS_x, -(A12_0 * RHS_y));
+      ay = detA * kid_fma(A11, RHS_y, -(A21_0 * RHS_x));
+    }
     uveln = kid_fma(dt, ax, u_star);
     vveln = kid_fma(dt, ay, v_star);
   }

@@ -147,13 +147,13 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     }
     if (__ballot(was_alive) == 0ull) continue;
     const int nstage = seg.R < KID_MAXRUN ? seg.R : KID_MAXRUN;
-    // lane q fetches packet elements q and q+64 of every distinct cell: where they live is fixed per lane
-    const PacketSrc s0 = packet_source(g, lane), s1 = packet_source(g, (lane < PK_SIZE - 64) ? 64 + lane : 0);
+    // lane q fetches packet elements q and q+64 of every distinct cell from the gathered packets (DevGrid::pkt)
+    const gdouble *gp = (const gdouble *)g.pkt + lane;
     for (int r = 0; r < nstage; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
       const int c = seg.cell[r];
       if (c >= 0) {
-        wpk[r * PK_STRIDE + lane] = *reinterpret_cast<const gdouble *>((const __attribute__((address_space(1))) char *)s0.base + (long long)c * s0.stride);
-        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = *reinterpret_cast<const gdouble *>((const __attribute__((address_space(1))) char *)s1.base + (long long)c * s1.stride);
+        wpk[r * PK_STRIDE + lane] = gp[(long long)c * PK_GSTRIDE];
+        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = gp[(long long)c * PK_GSTRIDE + 64];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

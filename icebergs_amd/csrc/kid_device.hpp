@@ -134,6 +134,10 @@ struct DevGrid {
   // pole, and the corners a strictly convex quadrilateral -- then "(xi, yj) inside the unit square" and the reference's
   // point-in-cell test (FW:6076-6160) are the same statement and the hot build tests the former (pack_static_kernel)
   const double *hotok;
+  // the cell packets themselves (PK_* layout, PK_GSTRIDE doubles per cell), gathered from the three record arrays once per
+  // forcing change (pack_packets_kernel): the hot build stages a cell with two contiguous loads per lane instead of
+  // resolving, per lane, which record of which neighbour cell element q lives in and loading from 64 different records
+  const double *pkt;
   // Parameter-only subexpressions of the hot loop, evaluated once on the host with the same IEEE operations (so the
   // results are the ones every lane used to compute for itself, per RK4 stage): sin(pi/180*lat_ref) alone was 7 % of
   // the step
@@ -160,7 +164,8 @@ struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; 
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) int lds_int;
-enum { PK_VEL = 0, PK_CORNER = 32, PK_T0 = 40, PK_DDX = 45, PK_DDY = 51, PK_AREA = 57, PK_MSK = 58, PK_HOTOK = 67, PK_SIZE = 68, PK_STRIDE = 68 };
+enum { PK_VEL = 0, PK_CORNER = 32, PK_T0 = 40, PK_DDX = 45, PK_DDY = 51, PK_AREA = 57, PK_MSK = 58, PK_HOTOK = 67, PK_SIZE = 68, PK_STRIDE = 68,
+       PK_GSTRIDE = 72 };   // doubles between two cells' packets in DevGrid::pkt (576 B: whole 64-byte lines)
 struct Corners { double lon00, lat00, lon10, lat10, lon11, lat11, lon01, lat01; };
 
 struct GlbCell {

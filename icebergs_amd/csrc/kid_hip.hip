@@ -65,6 +65,21 @@ __global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec 
   hotok[c] = ok;
 }
 
+// The cell packets of the hot build (kid_device.hpp, PK_*): one lane per (cell, element) copies the element from where
+// packet_source() says it lives.  Cells on the rim of the data domain have no complete neighbourhood and are never hot
+// (hotok = 0): only that flag is written for them.  Runs after pack_forcing_kernel (it reads the neighbours' records).
+__global__ void __launch_bounds__(256) pack_packets_kernel(const DevGrid g, double *__restrict__ pkt, const long long ncell) {
+  const long long t = (long long)blockIdx.x * 256ll + threadIdx.x;
+  const long long c = t / PK_GSTRIDE;
+  const int q = (int)(t - c * PK_GSTRIDE);
+  if (c >= ncell || q >= PK_SIZE) return;
+  const int i = (int)(c % g.ni), j = (int)(c / g.ni);
+  const bool interior = i >= 1 && i < g.ni - 1 && j >= 1 && j < g.nj - 1;
+  double v = 0.;
+  if (interior || q == PK_HOTOK) { const PacketSrc s = packet_source(g, q); v = *reinterpret_cast<const double *>(s.base + c * s.stride); }
+  pkt[t] = v;
+}
+
 // Optional extras fused into the per-cell prepass (kid_step_prepare): keep a copy of the ssh plane, zero the cell's
 // entries of the first `zero_planes` accumulator planes, zero two redo counters -- one launch instead of five.
 struct PrepExtras { double *ssh_copy; double *acc; int zero_planes; int *cnt0, *cnt1; };
@@ -353,6 +368,7 @@ struct kid_handle {
   int side_mode = 0; int *d_lane = nullptr, *d_lane_alt = nullptr; hipEvent_t evR = nullptr; int lane_step = 1; bool lanes_active = false, carry_valid = false, evC_live = false;
   hipEvent_t evC = nullptr, evP = nullptr;
   VelRec *d_vel2 = nullptr; TrcRec *d_trc2 = nullptr; DevGrid *d_grid2 = nullptr; int forc_parity = 0;  // forcing records of the odd steps
+  double *d_pkt[2] = {nullptr, nullptr};   // gathered cell packets of the hot build, one set per parity of the forcing records
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   unsigned fl_step = 0;                  // footloose passes so far: third counter word of the child-placement generator (kid_rng.h)
   int *d_fl_cursor = nullptr;
@@ -409,6 +425,7 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.isc = h->gd.isc; g.iec = h->gd.iec; g.jsc = h->gd.jsc; g.jec = h->gd.jec;
   g.ni = h->ni; g.nj = h->nj; g.latlon = h->gd.grid_is_latlon; g.regular = h->gd.grid_is_regular; g.Lx = h->gd.Lx;
   g.vel = h->forc_parity ? h->d_vel2 : h->d_vel; g.trc = h->forc_parity ? h->d_trc2 : h->d_trc; g.geo = h->d_geo; g.hotok = h->d_hotok;
+  g.pkt = h->d_pkt[h->forc_parity ? 1 : 0];
   g.dx = h->d_static[KID_G_DX]; g.dy = h->d_static[KID_G_DY]; g.ocean_depth = h->d_static[KID_G_OCEAN_DEPTH];
   g.ssh = h->d_forcing[KID_F_SSH];
   g.sin_lat_ref = sin((h->params.pi / 180.) * h->params.lat_ref);
@@ -533,6 +550,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_grid2, sizeof(DevGrid)));
   KID_HIP(h, hipMalloc(&h->d_vel2, h->ncell * sizeof(VelRec)));
   KID_HIP(h, hipMalloc(&h->d_trc2, h->ncell * sizeof(TrcRec)));
+  for (int q = 0; q < 2; ++q) { KID_HIP(h, hipMalloc(&h->d_pkt[q], (size_t)h->ncell * PK_GSTRIDE * sizeof(double))); KID_HIP(h, hipMemset(h->d_pkt[q], 0, (size_t)h->ncell * PK_GSTRIDE * sizeof(double))); }
   KID_HIP(h, hipMalloc(&h->d_lane, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipMemset(h->d_lane, 0, (size_t)capacity * sizeof(int)));
   KID_HIP(h, hipEventCreateWithFlags(&h->evC, hipEventDisableTiming)); KID_HIP(h, hipEventCreateWithFlags(&h->evP, hipEventDisableTiming));
@@ -593,6 +611,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_grid2) (void)hipFree(h->d_grid2);
   if (h->d_vel2) (void)hipFree(h->d_vel2);
   if (h->d_trc2) (void)hipFree(h->d_trc2);
+  for (int q = 0; q < 2; ++q) if (h->d_pkt[q]) (void)hipFree(h->d_pkt[q]);
   if (h->d_lane) (void)hipFree(h->d_lane);
   if (h->d_lane_alt) (void)hipFree(h->d_lane_alt);
   if (h->d_spread_mass_old_own) (void)hipFree(h->d_spread_mass_old_own);
@@ -711,6 +730,13 @@ int kid_sync(kid_handle *h) {
   return KID_OK;
 }
 
+// gather the cell packets of the current parity from the record arrays (after either of them has changed)
+static int pack_packets(kid_handle *h) {
+  const long long lanes = (long long)h->ncell * PK_GSTRIDE;
+  hipLaunchKernelGGL(pack_packets_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), h->d_pkt[h->forc_parity ? 1 : 0], (long long)h->ncell);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
 static int pack_static(kid_handle *h) {
   GridPlanes gp;
   for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
@@ -718,7 +744,7 @@ static int pack_static(kid_handle *h) {
   const int nb = (int)((h->ncell + 255) / 256);
   hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, h->d_hotok, h->ni, h->nj, (int)h->gd.grid_is_latlon, h->gd.Lx);
   KID_HIP(h, hipGetLastError());
-  return KID_OK;
+  return h->have_forcing ? pack_packets(h) : KID_OK;   // (the other parity's packets are rebuilt by the pack_forcing that precedes their use)
 }
 // src[k]: where forcing plane k currently lives on the device (the handle's own copy, or the caller's buffer)
 static int pack_forcing(kid_handle *h, const double *const src[KID_NFORCING], const PrepExtras ex = PrepExtras{nullptr, nullptr, 0, nullptr, nullptr}) {
@@ -729,8 +755,7 @@ static int pack_forcing(kid_handle *h, const double *const src[KID_NFORCING], co
   // a side stream is in use: general-build launches of the previous step may still read its records -> alternate two sets
   if (h->side_mode == 2 || h->pipelined) h->forc_parity ^= 1;
   hipLaunchKernelGGL(pack_forcing_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->forc_parity ? h->d_vel2 : h->d_vel, h->forc_parity ? h->d_trc2 : h->d_trc, h->ni, h->nj, ex);
-  KID_HIP(h, hipGetLastError());
-  return KID_OK;
+  return pack_packets(h);
 }
 
 int kid_set_static_grid(kid_handle *h, const double *const fields[KID_NGRID_STATIC]) {

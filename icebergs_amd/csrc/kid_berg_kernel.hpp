@@ -83,6 +83,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   // holds -- or spills -- them in vector registers)
   long long tid = (long long)blockIdx.x * bdim + threadIdx.x;
   for (bool first = true; FAST ? first : (tid - threadIdx.x < total); first = false, tid += (long long)gridDim.x * bdim) {
+  KID_TICK(-1);
   const bool inrange = tid < total;
   const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
@@ -238,7 +239,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     }
   }
   KID_PHASE_FENCE();
-  KID_MARK("evolve_done");
+  KID_MARK("evolve_done"); KID_TICK(6);
 
   if (PH & PH_FL) {  // footloose_calving (IB:5453, 2503-2734) on the berg's own rows between its evolve and its thermodynamics:
     // per berg the reference's order is evolve -> footloose -> thermodynamics too, and nothing of another berg is read.
@@ -285,7 +286,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
         if (PH & PH_INTERP) e.od = od_keep;
       }
       KID_PHASE_FENCE();
-      KID_MARK("thermo_interp_done");
+      KID_MARK("thermo_interp_done"); KID_TICK(7);
       const BergThermo before = t;
       if constexpr ((PH & PH_TSPREAD) != 0) {  // thermodynamics spreads the would-be masses itself, IB:3219-3238
         const TSpreadArgs ts{d.xi, d.yj, b.orient ? b.orient[kk] : p.initial_orientation, Fl<K>::footprint(fl) != 0};
@@ -304,7 +305,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
         }
       }
       KID_PHASE_FENCE();
-      KID_MARK("thermo_done");
+      KID_MARK("thermo_done"); KID_TICK(8);
     }
     if (PH & PH_SPREAD) {  // calculate_mass_on_ocean IB:4989-5009 on the post-thermodynamics state
       const bool act2 = t.alive && !skipped;
@@ -314,7 +315,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       if (!Fl<K>::no_diag(fl)) berg_diagnostics<K>(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
     seg_flush(seg, acc, ncell);
-    KID_MARK("spread_done");
+    KID_MARK("spread_done"); KID_TICK(9);
   }
 
   if (was_alive && !skipped) {
@@ -328,6 +329,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   }
   const unsigned long long be = __ballot(err != 0);
   if (be && __lane_id() == 0) unsafeAtomicAdd(scal + KID_S_ERROR_COUNT, (double)__popcll(be));
+  KID_TICK(10); KID_TICK(99);
   }  // grid-stride loop
 }
 

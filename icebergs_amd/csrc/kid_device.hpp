@@ -16,7 +16,7 @@ namespace kid {
 // Measurement-only macros (KID_EXP_*) change what the library computes or how it is laid out; they are honoured only
 // together with -DKID_EXPERIMENTS, which kid_version() reports, so that a stray -D cannot ship wrong answers silently.
 #if !defined(KID_EXPERIMENTS) && (defined(KID_EXP_MARKERS) || defined(KID_EXP_NO_ATOMICS) || defined(KID_EXP_MAXRUN) || defined(KID_EXP_CHUNK) || defined(KID_EXP_NUM_VGPR) || \
-                                  defined(KID_EXP_MTS_NOPAIR))
+                                  defined(KID_EXP_MTS_NOPAIR) || defined(KID_EXP_TIMING))
 #error "KID_EXP_* macros are measurement-only: build with -DKID_EXPERIMENTS to use them"
 #endif
 // Keeps the machine scheduler from interleaving two long phases (each wants ~100 VGPRs for its own loads in
@@ -27,6 +27,33 @@ namespace kid {
 #define KID_MARK(name) ((void)0)
 #endif
 #define KID_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// -DKID_EXPERIMENTS -DKID_EXP_TIMING: where a wave of the per-berg kernel spends its lifetime.  KID_TICK(n) charges the cycles
+// since the previous tick (s_memtime) to segment n in a per-wave LDS table; the wave adds its table to kid_tprof[] when it
+// ends (kid_exp_timing() reads it out, tools/profiling/time_segments.py prints the shares).  Measurement only.
+#ifdef KID_EXP_TIMING
+enum { KID_TPROF_WAVES = 262144 };
+__device__ unsigned long long kid_tprof[KID_TPROF_WAVES * 16];   // one row per wave of a launch (no atomics: nothing shared between waves)
+__device__ __forceinline__ void kid_tick(int idx) {   // idx < 0: start the clock; idx == 99: add the wave's table to its row
+  __shared__ unsigned long long tl[4][16];
+  const unsigned long long now = __builtin_readcyclecounter();
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    if (idx < 0) { for (int q = 0; q < 16; ++q) tl[w][q] = 0ull; }
+    else if (idx == 99) {
+      const unsigned long long row = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)w;
+      if (gridDim.x > 4096u && row < (unsigned long long)KID_TPROF_WAVES) {   // (the hot build's launches only: the general build's grid is small)
+        unsigned long long *r = kid_tprof + row * 16ull;
+        r[0] += 1ull;
+        for (int q = 1; q < 16; ++q) r[q] += tl[w][q];
+      }
+    } else tl[w][1 + idx] += now - tl[w][0];
+    tl[w][0] = now;
+  }
+}
+#define KID_TICK(n) kid_tick(n)
+#else
+#define KID_TICK(n) ((void)0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // Namelist switches as the device code sees them.  K = 0: read from kid_params at run time (any namelist).
@@ -808,24 +835,24 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   double s_lat1 = 0., c_lat1 = 1.;
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
-    KID_MARK("loop_top");
+    KID_MARK("loop_top"); KID_TICK(s == 0 ? 0 : 5);
     if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST, K>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
     KID_PHASE_FENCE();
-    KID_MARK("after_adjust");
+    KID_MARK("after_adjust"); KID_TICK(1);
     LatTerms lt;
     if (s == 0) { lt = lat_terms<K>(g, p, lat_s, sin_ref); s_lat1 = lt.s; c_lat1 = lt.c; }
     else lt = lat_terms_near<K>(g, p, lat_s, sin_ref, lat1, s_lat1, c_lat1);
     double qu = uvel_s * lt.dxdl, qv = vvel_s * dydl;          // u_k, v_k  IB:7412
     KID_PHASE_FENCE();
     double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
-    KID_MARK("after_latterms");
+    KID_MARK("after_latterms"); KID_TICK(2);
     if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e, need_ice);
     if constexpr (!PRE_ONCE) ap = accel_pre<K>(g, p, bg, e.hi, e.od);
     KID_PHASE_FENCE();
-    KID_MARK("after_interp");
+    KID_MARK("after_interp"); KID_TICK(3);
     accel<true, K>(g, p, ap, e, i, j, lt.sin_f, uvel_s, vvel_s, uvel1, vvel1, (s < 2) ? dt_2 : dt, ax, ay, axn_s, ayn_s, bxn, byn, tickets);
     KID_PHASE_FENCE();
-    KID_MARK("after_accel");
+    KID_MARK("after_accel"); KID_TICK(4);
     double qax = ax, qay = ay, qaxn = axn_s, qayn = ayn_s;
     if (on_tang) {
       qu = xdot_s; qv = ydot_s;
@@ -856,7 +883,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
       }
     }
   }
-  KID_MARK("loop_end");
+  KID_MARK("loop_end"); KID_TICK(5);
   // combine IB:7597-7616
   double lonn, latn, uveln, vveln, axn, ayn;
   if (on_tang) {

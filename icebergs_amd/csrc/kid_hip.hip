@@ -500,6 +500,22 @@ int64_t kid_sizeof(int which) {
                    case 4: return (int64_t)sizeof(kid_forcing_in);
                    case 5: return (int64_t)sizeof(kid_calving_params); case 6: return (int64_t)sizeof(kid_calving_in); default: return -1; }
 }
+#ifdef KID_EXP_TIMING
+// measurement build only: the segment clock of the per-berg kernels (kid_device.hpp, KID_TICK); out[0] = waves, out[1+n] = cycles of segment n
+int kid_exp_timing(unsigned long long *out, int reset) {
+  if (out) {
+    std::vector<unsigned long long> all((size_t)KID_TPROF_WAVES * 16);
+    if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(kid_tprof), all.size() * sizeof(unsigned long long)) != hipSuccess) return KID_EHIP;
+    for (int q = 0; q < 16; ++q) out[q] = 0ull;
+    for (size_t r = 0; r < (size_t)KID_TPROF_WAVES; ++r) for (int q = 0; q < 16; ++q) out[q] += all[r * 16 + q];
+  }
+  if (reset) {
+    void *sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(kid_tprof)) != hipSuccess || hipMemset(sym, 0, (size_t)KID_TPROF_WAVES * 16 * sizeof(unsigned long long)) != hipSuccess) return KID_EHIP;
+  }
+  return KID_OK;
+}
+#endif
 const char *kid_last_error(const kid_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capacity, int device, kid_handle **out) {

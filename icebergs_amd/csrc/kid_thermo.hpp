@@ -77,28 +77,49 @@ __device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *int
   __builtin_amdgcn_wave_barrier();
   return s;
 }
+// One lane per (staged slot, run) used to sum its run's values one after the other: with the SoA in cell order a wave holds
+// one or two runs of 30-60 lanes, so a dozen lanes each walked a chain of dependent LDS reads and adds 60 long while the
+// rest of the wave idled -- 14 % of a wave's lifetime in the hot build (tools/profiling/time_segments.py).  Now a run is cut
+// into P = 1, 2 or 4 pieces summed by neighbouring lanes (P the largest that still fits the wave's 64 lanes), the pieces are
+// added in order ((p0 + p1) + p2) + p3 through two shuffles and the first piece's lane issues the atomic.  Still a fixed
+// order of additions for a given arrangement of the lanes.
 __device__ __noinline__ void seg_flush_impl(lds_double *val, lds_int *head, lds_int *len, lds_int *cell, lds_int *plane,
                                             int R, unsigned M, int npend, double *acc, size_t ncell) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int lane = (int)__lane_id();
   const int nitems = npend * R;
-  for (int item = lane; item < nitems; item += 64) {
-    const int q = (int)(((unsigned)item * M) >> 16), r = item - q * R;
+  const int P = (nitems * 4 <= 64) ? 4 : ((nitems * 2 <= 64) ? 2 : 1);   // wave-uniform
+  const int lg = (P == 4) ? 2 : ((P == 2) ? 1 : 0);
+  for (int base = 0; base < nitems; base += (64 >> lg)) {
+    const int item = base + (lane >> lg), part = lane & (P - 1);
+    const bool live = item < nitems;
+    const int it = live ? item : 0;
+    const int q = (int)(((unsigned)it * M) >> 16), r = it - q * R;
     const int h = head[r], n = len[r], c = cell[r];
+    const int per = (n + P - 1) >> lg;                 // values per piece
+    const int t0 = part * per, t1 = (t0 + per < n) ? t0 + per : n;
     double sum = 0.;
     const lds_double *v = val + q * KID_ROW + h;
-    int t = 0;
-    for (; t + 4 <= n; t += 4) {  // four reads in flight; the adds stay in lane order
+    int t = t0;
+    for (; t + 4 <= t1; t += 4) {  // four reads in flight; the adds of a piece stay in lane order
       const double a0 = v[t], a1 = v[t + 1], a2 = v[t + 2], a3 = v[t + 3];
       sum += a0; sum += a1; sum += a2; sum += a3;
     }
-    {
+    if (t < t1) {
       const double a0 = v[t], a1 = v[t + 1], a2 = v[t + 2];  // reads past the run stay inside the staging block
-      if (t < n) sum += a0;
-      if (t + 1 < n) sum += a1;
-      if (t + 2 < n) sum += a2;
+      sum += a0;
+      if (t + 1 < t1) sum += a1;
+      if (t + 2 < t1) sum += a2;
     }
-    if (c >= 0 && sum != 0.) unsafeAtomicAdd(acc + (size_t)plane[q] * ncell + (size_t)c, sum);
+    if (P >= 2) {   // pieces of a run sit in neighbouring lanes: p0 + p1 (and p2 + p3), then (p0 + p1) + ... in order
+      const double s1 = __shfl_down(sum, 1);
+      if (P == 2) sum = sum + s1;
+      else {
+        const double s2 = __shfl_down(sum, 2), s3 = __shfl_down(sum, 3);
+        sum = ((sum + s1) + s2) + s3;
+      }
+    }
+    if (live && part == 0 && c >= 0 && sum != 0.) unsafeAtomicAdd(acc + (size_t)plane[q] * ncell + (size_t)c, sum);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }

@@ -149,12 +149,28 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     if (__ballot(was_alive) == 0ull) continue;
     const int nstage = seg.R < KID_MAXRUN ? seg.R : KID_MAXRUN;
     // lane q fetches packet elements q and q+64 of every distinct cell from the gathered packets (DevGrid::pkt)
+    // Eight cells at a time, all their loads issued before the first LDS write: written one cell per iteration every packet
+    // was a memory round trip of its own (the write waits for its load) -- 13 in a row for a wave of config 3's sparse
+    // population (5 bergs per cell), 58 % of that wave's lifetime (tools/profiling/time_segments_c3.py), and the reason the
+    // kernel slowed down as the cell order decayed between re-binnings.  (A run without a cell loads cell 0's packet and
+    // does not store it.)
     const gdouble *gp = (const gdouble *)g.pkt + lane;
-    for (int r = 0; r < nstage; ++r) {  // wave-uniform: one cooperative fetch per distinct cell
-      const int c = seg.cell[r];
-      if (c >= 0) {
-        wpk[r * PK_STRIDE + lane] = gp[(long long)c * PK_GSTRIDE];
-        if (lane < PK_SIZE - 64) wpk[r * PK_STRIDE + 64 + lane] = gp[(long long)c * PK_GSTRIDE + 64];
+    for (int r0 = 0; r0 < nstage; r0 += 8) {  // wave-uniform
+      int cc[8]; double a[8], a2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cc[u] = (r0 + u < nstage) ? seg.cell[r0 + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long off = (long long)(cc[u] >= 0 ? cc[u] : 0) * PK_GSTRIDE;
+        a[u] = gp[off];
+        a2[u] = gp[off + ((lane < PK_SIZE - 64) ? 64 : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (cc[u] >= 0) {
+          wpk[(r0 + u) * PK_STRIDE + lane] = a[u];
+          if (lane < PK_SIZE - 64) wpk[(r0 + u) * PK_STRIDE + 64 + lane] = a2[u];
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -184,6 +200,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     }
   }
 
+  if (!RK) KID_TICK(2);   // (Verlet builds: prologue + the interpolation before the evolve)
   if (PH & PH_EVOLVE) {  // IB:7081-7179
     const bool moves = was_alive && (t.static_berg < 0.5);
     if (moves) {

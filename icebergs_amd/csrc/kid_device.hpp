@@ -922,6 +922,7 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
   const double dydl = grid_latlon<K>(g) ? g.dydl : 1.;
   const double lon1 = d.lon, lat1 = d.lat, uvel1 = d.uvel, vvel1 = d.vvel;
   double axn = d.axn, ayn = d.ayn, bxn = d.bxn, byn = d.byn;
+  KID_TICK(0);
   d.uvel_prev = d.uvel - dt_2 * d.bxn; d.vvel_prev = d.vvel - dt_2 * d.byn;       // IB:7256
   const double uvel3 = uvel1 + (dt_2 * axn), vvel3 = vvel1 + (dt_2 * ayn);         // IB:7259-7260
   if constexpr (FAST) { if (!PkCell{pk}.hotok() || ((lat1 > 89.) && g.latlon)) { bail = true; return; } }
@@ -930,8 +931,10 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
   if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e);
   const AccelPre ap = accel_pre<K>(g, p, bg, e.hi, e.od);
   KID_PHASE_FENCE();
+  KID_TICK(3);
   double ax1, ay1, uveln, vveln;
   accel<false, K>(g, p, ap, e, d.ine, d.jne, lt.sin_f, uvel1, vvel1, uvel1, vvel1, dt, ax1, ay1, axn, ayn, bxn, byn, tickets);
+  KID_TICK(4);
   const bool on_tang = FAST ? false : ((lat1 > 89.) && g.latlon);
   if (on_tang) {
     double xdot3, ydot3, xddot1, yddot1;
@@ -954,6 +957,7 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
   }
   KID_PHASE_FENCE();
   adjust_index_and_ground<FAST, K>(g, p, pk, lonn, latn, d.ine, d.jne, d.xi, d.yj, err, bail);
+  KID_TICK(1);
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
 }
 

@@ -9,7 +9,9 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 grid, p, b = S.config_c2(n=n, seed=2)
 ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
 ib.upload_bergs(b); ib.set_store_environment(False)
-ib.run(3); ib.sync()
+age = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # steps without re-binning before the clock starts (how the profile changes as the cell order decays)
+if age: ib.set_resort_interval(0)
+ib.run(3 + age); ib.sync()
 lib = L.load()
 out = (C.c_ulonglong * 16)()
 lib.kid_exp_timing.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]

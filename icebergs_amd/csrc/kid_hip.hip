@@ -384,6 +384,7 @@ struct kid_handle {
   unsigned long long *d_key64[2] = {nullptr, nullptr}; int *d_rows[2] = {nullptr, nullptr};
   int *d_static_rows = nullptr; long long static_rows_n = -1, static_rows_cap = 0;   // rows ordered by the five static `inorder` keys (mts_build_order)
   unsigned long long *d_last_key = nullptr; int *d_order_flag = nullptr; long long order_n = -1;   // cell key of every row at the last sort: an unchanged population keeps its order
+  unsigned long long *d_bond_sig = nullptr; bool labels_stale = true;   // per-berg signature of what the conglomerate labelling reads (set_conglom_ids skips itself while nothing changes)
   MtsDev mts_shadow{}; bool mts_shadow_valid = false;   // what d_mts holds (the table is re-uploaded only when it differs)
   int conglom_batch = 8;                                // label-propagation sweeps launched before the first convergence check (set_conglom_ids)
   void *d_mts_tmp = nullptr; size_t mts_tmp_bytes = 0;
@@ -692,6 +693,7 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   }
   h->params = *params;
   h->tables_dirty = true;
+  h->labels_stale = true;   // (the conglomerate labelling reads dem / max_bonds / use_broken_bonds_for_substep_contact)
   h->flags.footprint = footprint_needed(h->params) ? 1 : 0;
   if (!h->params.old_interp_flds_order) h->flags.store_env = 1;  // the stored environment is an input again
   return KID_OK;

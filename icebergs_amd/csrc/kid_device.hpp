@@ -33,7 +33,7 @@ namespace kid {
 #ifdef KID_EXP_TIMING
 enum { KID_TPROF_WAVES = 262144 };
 __device__ unsigned long long kid_tprof[KID_TPROF_WAVES * 16];   // one row per wave of a launch (no atomics: nothing shared between waves)
-__device__ __forceinline__ void kid_tick(int idx) {   // idx < 0: start the clock; idx == 99: add the wave's table to its row
+__device__ __forceinline__ void kid_tick(int idx, int idx2 = 0) {   // idx < 0: start the clock; idx == 99: add the wave's table to its row
   __shared__ unsigned long long tl[4][16];
   const unsigned long long now = __builtin_readcyclecounter();
   if ((threadIdx.x & 63) == 0) {
@@ -41,7 +41,7 @@ __device__ __forceinline__ void kid_tick(int idx) {   // idx < 0: start the cloc
     if (idx < 0) { for (int q = 0; q < 16; ++q) tl[w][q] = 0ull; }
     else if (idx == 99) {
       const unsigned long long row = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)w;
-      if (gridDim.x > 4096u && row < (unsigned long long)KID_TPROF_WAVES) {   // (the hot build's launches only: the general build's grid is small)
+      if ((gridDim.x > 4096u || idx2) && row < (unsigned long long)KID_TPROF_WAVES) {   // (the hot build's launches only: the general build's grid is small; idx2: any grid)
         unsigned long long *r = kid_tprof + row * 16ull;
         r[0] += 1ull;
         for (int q = 1; q < 16; ++q) r[q] += tl[w][q];
@@ -51,8 +51,10 @@ __device__ __forceinline__ void kid_tick(int idx) {   // idx < 0: start the cloc
   }
 }
 #define KID_TICK(n) kid_tick(n)
+#define KID_TICK_ANY(n) kid_tick(n, 1)
 #else
 #define KID_TICK(n) ((void)0)
+#define KID_TICK_ANY(n) ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------

@@ -112,6 +112,9 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   // the first cell_add) instead of holding the registers -- or re-reading HBM -- across the RK4 loop.
   constexpr bool SCATTER_ = (PH & (PH_THERMO | PH_SPREAD)) != 0;
   constexpr bool PARK = FAST && SCATTER_ && (PH & PH_EVOLVE) != 0;
+  // footloose builds: what the footloose phase does not need either (bits, heat density, the bergy bits of the footloose bits)
+  // stays in its LDS row until the thermodynamics asks for it
+  constexpr bool LATE_PARK = PARK && (PH & PH_FL) != 0;
   double park_ms = 0., park_bits = 0., park_hd = 0., park_flk = 0., park_flbits = 0., park_flbergy = 0.;
   if constexpr (PARK) {
     park_ms = ldg(b.f[KID_B_MASS_SCALING], kk); park_bits = ldg(b.f[KID_B_MASS_OF_BITS], kk);
@@ -211,8 +214,9 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
         KID_PHASE_FENCE();
         const lds_double *row = seg.val + (int)__lane_id();
         t.M = row[0 * KID_ROW]; t.T = row[1 * KID_ROW]; t.W = row[2 * KID_ROW]; t.L = row[3 * KID_ROW];
-        park_ms = row[4 * KID_ROW]; park_bits = row[5 * KID_ROW]; park_hd = row[6 * KID_ROW];
-        if (Fl<K>::has_fl(fl)) { park_flk = row[7 * KID_ROW]; park_flbits = row[8 * KID_ROW]; park_flbergy = row[9 * KID_ROW]; }
+        park_ms = row[4 * KID_ROW];
+        if constexpr (!LATE_PARK) { park_bits = row[5 * KID_ROW]; park_hd = row[6 * KID_ROW]; }
+        if (Fl<K>::has_fl(fl)) { park_flk = row[7 * KID_ROW]; park_flbits = row[8 * KID_ROW]; if constexpr (!LATE_PARK) park_flbergy = row[9 * KID_ROW]; }
       }
       if (FAST && bail) {  // hand this berg to the general build; nothing of it has been written yet
         const int slot = atomicAdd(redo.count, 1);
@@ -268,7 +272,10 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
       if constexpr (PARK) {
         bool touched = false;
         footloose_core(g, p, b, cx, kk, d.ine, d.jne, CellOf<FAST>::make(g, pk, d.ine, d.jne).area(), park_ms, t.static_berg, t.M, t.T, t.W, t.L, park_flk, park_flbits, touched, acc, ncell, scal);
-        if (touched) { park_flbits = ldg(b.f[KID_B_MASS_OF_FL_BITS], kk); park_flbergy = ldg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk); }
+        if (touched) {
+          park_flbits = ldg(b.f[KID_B_MASS_OF_FL_BITS], kk); park_flbergy = ldg(b.f[KID_B_MASS_OF_FL_BERGY_BITS], kk);
+          if constexpr (LATE_PARK) seg.val[(int)__lane_id() + 9 * KID_ROW] = park_flbergy;
+        }
       } else {
         footloose_one(g, p, b, cx, kk, acc, ncell, scal);
         t.M = ldg(b.f[KID_B_MASS], kk); t.T = ldg(b.f[KID_B_THICKNESS], kk); t.W = ldg(b.f[KID_B_WIDTH], kk); t.L = ldg(b.f[KID_B_LENGTH], kk);
@@ -280,6 +287,11 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
     const bool active = t.alive && !skipped;
     if (!FAST) seg = make_runs(active ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);  // cells may have changed
     const typename CellOf<FAST>::type cellv = CellOf<FAST>::make(g, pk, d.ine, d.jne);
+    if constexpr (LATE_PARK) {
+      const lds_double *row = seg.val + (int)__lane_id();
+      park_bits = row[5 * KID_ROW]; park_hd = row[6 * KID_ROW];
+      if (Fl<K>::has_fl(fl)) park_flbergy = row[9 * KID_ROW];
+    }
     if constexpr (PARK) { t.mass_scaling = park_ms; t.mass_of_bits = park_bits; t.heat_density = park_hd; }
     else {
       t.mass_scaling = ldg(b.f[KID_B_MASS_SCALING], kk);

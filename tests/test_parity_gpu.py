@@ -326,6 +326,22 @@ def test_c4_mts_dem(oracle, case):
         assert (refbd["broken"] != 0).sum() > 0  # the case does fracture
 
 
+@pytest.mark.parametrize("case", ["hex_grounded", "two_bergs"])
+def test_c4_fused_substeps_match_three_launches(oracle, case, monkeypatch):
+    """The sub-step loop in one cooperative launch (mts_substeps_kernel: records exchanged point to point, the pair force in
+    pieces) against the same loop as three launches per sub-step (KID_MTS_NO_FUSED): the same bonds break in the same
+    sub-steps, conglomerates come out the same, states agree to the DEM tolerances."""
+    kw = {"hex_grounded": dict(), "two_bergs": dict(bump=(150e3, 150e3), two_bergs=True, hexagonal=False, nx=4, ny=6)}[case]
+    grid, p, b, bd = S.config_c4(**kw)
+    S.set_diag_all(p)
+    fused, fusedbd = P.run_hip_mts(grid, p, b, bd, 6)
+    monkeypatch.setenv("KID_MTS_NO_FUSED", "1")
+    plain, plainbd = P.run_hip_mts(grid, p, b, bd, 6)
+    P.compare_mts(plain, plainbd, fused, fusedbd, "C4 fused vs three launches/" + case)
+    if case == "hex_grounded":
+        assert (fusedbd["broken"] != 0).sum() > 0
+
+
 @pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag", "slow_lane_verlet", "slow_lane_new_order"])
 def test_pipelined_stepper_matches_plain(oracle, split_general):
     """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)

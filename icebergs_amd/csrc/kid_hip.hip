@@ -65,19 +65,43 @@ __global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec 
   hotok[c] = ok;
 }
 
-// The cell packets of the hot build (kid_device.hpp, PK_*): one lane per (cell, element) copies the element from where
-// packet_source() says it lives.  Cells on the rim of the data domain have no complete neighbourhood and are never hot
-// (hotok = 0): only that flag is written for them.  Runs after pack_forcing_kernel (it reads the neighbours' records).
-__global__ void __launch_bounds__(256) pack_packets_kernel(const DevGrid g, double *__restrict__ pkt, const long long ncell) {
-  const long long t = (long long)blockIdx.x * 256ll + threadIdx.x;
-  const long long c = t / PK_GSTRIDE;
-  const int q = (int)(t - c * PK_GSTRIDE);
-  if (c >= ncell || q >= PK_SIZE) return;
-  const int i = (int)(c % g.ni), j = (int)(c / g.ni);
-  const bool interior = i >= 1 && i < g.ni - 1 && j >= 1 && j < g.nj - 1;
-  double v = 0.;
-  if (interior || q == PK_HOTOK) { const PacketSrc s = packet_source(g, q); v = *reinterpret_cast<const double *>(s.base + c * s.stride); }
-  pkt[t] = v;
+// The cell packets of the hot build (kid_device.hpp, PK_*).  A wave takes one row of cells at a time, lane q copying
+// elements q and q + 64 of a cell from where packet_source() says they live -- resolved once per lane, as in the hot
+// build's own staging before the packets were gathered -- for KID_PKT_CELLS_PER_WAVE consecutive cells, eight loads in
+// flight.  (One lane per (cell, element) with the index arithmetic done per lane was ~150 instructions per element: 0.65 ms
+// for the 2000 x 1000 grid of config 3, compute-bound; this is the bandwidth of 576 B written per cell.)  Cells on the rim
+// of the data domain have no complete neighbourhood and are never hot (hotok = 0): only that flag is written for them.
+// Runs after pack_forcing_kernel (it reads the neighbours' records).
+enum { KID_PKT_CELLS_PER_WAVE = 32 };
+__global__ void __launch_bounds__(256) pack_packets_kernel(const DevGrid g, double *__restrict__ pkt) {
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  const int j = (int)blockIdx.y;
+  const int i0 = ((int)blockIdx.x * 4 + wave) * KID_PKT_CELLS_PER_WAVE;
+  if (i0 >= g.ni) return;
+  const bool second = lane < PK_SIZE - 64;
+  const PacketSrc s0 = packet_source(g, lane), s1 = packet_source(g, second ? 64 + lane : 0);
+  const bool row_inside = j >= 1 && j < g.nj - 1;
+  const int i1 = min(i0 + KID_PKT_CELLS_PER_WAVE, g.ni);
+  for (int ib = i0; ib < i1; ib += 8) {
+    double a[8], a2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = ib + u;
+      const bool interior = row_inside && i >= 1 && i < g.ni - 1 && i < i1;
+      const long long c = interior ? (long long)j * g.ni + i : (long long)g.ni + 1;   // (a cell whose whole neighbourhood exists)
+      a[u] = *reinterpret_cast<const double *>(s0.base + c * s0.stride);
+      a2[u] = *reinterpret_cast<const double *>(s1.base + c * s1.stride);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = ib + u;
+      if (i >= i1) continue;
+      const bool interior = row_inside && i >= 1 && i < g.ni - 1;
+      double *o = pkt + ((long long)j * g.ni + i) * PK_GSTRIDE;
+      o[lane] = interior ? a[u] : 0.;
+      if (second) o[64 + lane] = interior ? a2[u] : ((64 + lane == PK_HOTOK) ? g.hotok[(long long)j * g.ni + i] : 0.);
+    }
+  }
 }
 
 // Optional extras fused into the per-cell prepass (kid_step_prepare): keep a copy of the ssh plane, zero the cell's
@@ -750,8 +774,8 @@ int kid_sync(kid_handle *h) {
 
 // gather the cell packets of the current parity from the record arrays (after either of them has changed)
 static int pack_packets(kid_handle *h) {
-  const long long lanes = (long long)h->ncell * PK_GSTRIDE;
-  hipLaunchKernelGGL(pack_packets_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), h->d_pkt[h->forc_parity ? 1 : 0], (long long)h->ncell);
+  const unsigned bx = (unsigned)((h->ni + 4 * KID_PKT_CELLS_PER_WAVE - 1) / (4 * KID_PKT_CELLS_PER_WAVE));
+  hipLaunchKernelGGL(pack_packets_kernel, dim3(bx, (unsigned)h->nj), dim3(256), 0, h->stream, dev_grid(h), h->d_pkt[h->forc_parity ? 1 : 0]);
   KID_HIP(h, hipGetLastError());
   return KID_OK;
 }

@@ -29,6 +29,15 @@ module kid_hip_mod
   public :: kid_set_footloose_step, kid_get_footloose_step
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
+  ! every entry point of include/kid.h is usable from Fortran (tests/test_abi.py checks the list against the header)
+  public :: kid_bond_soa, kid_accum_device_ptr, kid_bind_accum_buffer, kid_bind_spread_mass_old, kid_download_bonds
+  public :: kid_evolve_icebergs_interactive, kid_evolve_icebergs_mts, kid_footloose_uniform, kid_get_iceberg_counter
+  public :: kid_last_error, kid_last_redo_count, kid_move_berg_between_cells, kid_num_bond_traj_records
+  public :: kid_num_traj_records, kid_profile_enable, kid_profile_get, kid_restart_count_bergs
+  public :: kid_restart_read_bergs, kid_restart_read_bonds, kid_restart_write_bergs, kid_restart_write_bonds
+  public :: kid_set_conglom_ids, kid_set_forcing_device, kid_set_iceberg_counter, kid_set_resort_interval
+  public :: kid_set_side_stream, kid_set_store_environment, kid_set_stream, kid_sizeof, kid_step_prepare
+  public :: kid_upload_bonds, kid_version
 
   interface
     integer(c_int) function kid_create(grid, params, capacity, device, handle) bind(C, name='kid_create')
@@ -193,6 +202,104 @@ module kid_hip_mod
     integer(c_int) function kid_compact_bergs(h) bind(C, name='kid_compact_bergs')
       import :: c_int, c_ptr
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_move_berg_between_cells(h) bind(C, name='kid_move_berg_between_cells')   ! IB:5437
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function kid_set_resort_interval(h, steps) bind(C, name='kid_set_resort_interval')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: steps
+    end function
+    type(c_ptr) function kid_version() bind(C, name='kid_version')   ! a NUL-terminated string: the library and its build switches
+      import :: c_ptr
+    end function
+    integer(c_int64_t) function kid_sizeof(which) bind(C, name='kid_sizeof')   ! ABI layout check against c_sizeof of the types below
+      import :: c_int, c_int64_t
+      integer(c_int), value :: which
+    end function
+    integer(c_int) function kid_set_stream(h, hip_stream) bind(C, name='kid_set_stream')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h, hip_stream
+    end function
+    integer(c_int) function kid_set_forcing_device(h, dev_fields) bind(C, name='kid_set_forcing_device')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      type(c_ptr), intent(in) :: dev_fields(*)
+    end function
+    integer(c_int) function kid_accum_device_ptr(h, dev_ptr, count) bind(C, name='kid_accum_device_ptr')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      type(c_ptr), intent(out) :: dev_ptr
+      integer(c_int64_t), intent(out) :: count
+    end function
+    integer(c_int) function kid_bind_accum_buffer(h, dev_ptr, count) bind(C, name='kid_bind_accum_buffer')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h, dev_ptr
+      integer(c_int64_t), value :: count
+    end function
+    integer(c_int) function kid_bind_spread_mass_old(h, dev_ptr, count) bind(C, name='kid_bind_spread_mass_old')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h, dev_ptr
+      integer(c_int64_t), value :: count
+    end function
+    real(c_double) function kid_footloose_uniform(seed, berg_id, step, draw) bind(C, name='kid_footloose_uniform')
+      import :: c_double, c_int32_t, c_int64_t
+      integer(c_int32_t), value :: seed, draw
+      integer(c_int64_t), value :: berg_id, step
+    end function
+    integer(c_int) function kid_num_traj_records(h, n) bind(C, name='kid_num_traj_records')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: n
+    end function
+    integer(c_int) function kid_num_bond_traj_records(h, n) bind(C, name='kid_num_bond_traj_records')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: n
+    end function
+    integer(c_int) function kid_profile_enable(h, on) bind(C, name='kid_profile_enable')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function
+    integer(c_int) function kid_profile_get(h, berg_kernel_ms_total, berg_kernel_launches, all_ms_total) bind(C, name='kid_profile_get')
+      import :: c_int, c_ptr, c_double, c_int64_t
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: berg_kernel_ms_total, all_ms_total
+      integer(c_int64_t), intent(out) :: berg_kernel_launches
+    end function
+    ! the restart files without a handle (host arrays in, host arrays out): what kid_write_restart / kid_read_restart are made of
+    integer(c_int) function kid_restart_count_bergs(path, n) bind(C, name='kid_restart_count_bergs')
+      import :: c_int, c_char, c_int64_t
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int64_t), intent(out) :: n
+    end function
+    integer(c_int) function kid_restart_write_bergs(path, p, host) bind(C, name='kid_restart_write_bergs')
+      import :: c_int, c_char, kid_params, kid_berg_soa
+      character(kind=c_char), intent(in) :: path(*)
+      type(kid_params), intent(in) :: p
+      type(kid_berg_soa), intent(in) :: host
+    end function
+    integer(c_int) function kid_restart_read_bergs(path, host, capacity) bind(C, name='kid_restart_read_bergs')
+      import :: c_int, c_char, c_int64_t, kid_berg_soa
+      character(kind=c_char), intent(in) :: path(*)
+      type(kid_berg_soa), intent(inout) :: host
+      integer(c_int64_t), value :: capacity
+    end function
+    integer(c_int) function kid_restart_write_bonds(path, p, bergs, bonds) bind(C, name='kid_restart_write_bonds')
+      import :: c_int, c_char, kid_params, kid_berg_soa, kid_bond_soa
+      character(kind=c_char), intent(in) :: path(*)
+      type(kid_params), intent(in) :: p
+      type(kid_berg_soa), intent(in) :: bergs
+      type(kid_bond_soa), intent(in) :: bonds
+    end function
+    integer(c_int) function kid_restart_read_bonds(path, bergs, bonds) bind(C, name='kid_restart_read_bonds')
+      import :: c_int, c_char, kid_berg_soa, kid_bond_soa
+      character(kind=c_char), intent(in) :: path(*)
+      type(kid_berg_soa), intent(in) :: bergs
+      type(kid_bond_soa), intent(inout) :: bonds
     end function
     integer(c_int) function kid_zero_accumulators(h) bind(C, name='kid_zero_accumulators')          ! IB:5125-5156
       import :: c_int, c_ptr

@@ -67,3 +67,22 @@ def test_structs_have_no_implicit_padding():
     from icebergs_amd import types as T
     for cls in (T.Params, T.GridDesc, T.BergSoA, T.BondSoA, T.ForcingIn, T.CalvingParams, T.CalvingIn, T.TrajParams):
         assert ctypes.sizeof(cls) == sum(ctypes.sizeof(t) for _, t in cls._fields_), cls.__name__
+
+
+def test_fortran_module_covers_the_header():
+    """Every entry point of include/kid.h has a bind(C) interface in the Fortran module (the host language north_star names) and
+    is public there, and every type of include/kid_types.h that crosses the boundary is exported."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "kid.h")).read()
+    mod = open(os.path.join(root, "icebergs_amd", "fortran", "kid_hip_mod.F90")).read()
+    inc = open(os.path.join(root, "icebergs_amd", "fortran", "kid_types_gen.inc")).read()
+    entry = set(re.findall(r"\b(kid_[a-z0-9_]+)\s*\(", hdr))
+    binds = set(re.findall(r"bind\(C, name='(kid_[a-z0-9_]+)'\)", mod))
+    public = set()
+    for m in re.finditer(r"^\s*public ::(.*)$", mod, re.M):
+        public |= {x.strip() for x in m.group(1).split(",")}
+    types = set(re.findall(r"type, bind\(C\) :: (\w+)", inc))
+    assert not (entry - binds - types), sorted(entry - binds - types)     # (a type's name followed by '(' is a cast in a comment, not a function)
+    assert not (binds - public), sorted(binds - public)
+    assert not (types - public), sorted(types - public)

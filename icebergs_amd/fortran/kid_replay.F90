@@ -6,7 +6,12 @@
 !!   int32 magic(=1263093761), kid_grid_desc, kid_params, int32 nsteps, int32 mode(0 fused, 1 phase by phase),
 !!   int64 n, KID_NGRID_STATIC planes, KID_NFORCING planes (ni*nj fp64 each), KID_NB_F64 arrays of n fp64,
 !!   KID_NB_I32 arrays of n int32, n int64 ids.
-!! Output file: int64 n_slots, the berg arrays in the same order, KID_NACC + KID_NOUT planes, KID_NSCALAR scalars.
+!! With magic 1263093762 a bonds section follows (bonded conglomerates, IB:5409-5431): int32 max_bonds, n int32 counts,
+!!   max_bonds*n int64 partner ids, max_bonds*n int32 broken marks, KID_NBOND_F64 arrays of max_bonds*n fp64 (slot-major,
+!!   include/kid_types.h kid_bond_soa) -- uploaded with kid_upload_bonds, stepped with kid_run_step (which dispatches to
+!!   the MTS / DEM path), downloaded with kid_download_bonds.
+!! Output file: int64 n_slots, the berg arrays in the same order, KID_NACC + KID_NOUT planes, KID_NSCALAR scalars
+!!   (and, with bonds, the counts, partner ids, broken marks and bond fields as they came back).
 program kid_replay
   use, intrinsic :: iso_c_binding
   use kid_hip_mod
@@ -15,7 +20,13 @@ program kid_replay
   type(kid_grid_desc) :: gd
   type(kid_params) :: par
   type(kid_berg_soa) :: soa
+  type(kid_bond_soa) :: bsoa
   type(c_ptr) :: h
+  logical :: with_bonds
+  integer(c_int32_t) :: mb
+  integer(c_int32_t), allocatable, target :: bcount(:), bbroken(:,:)
+  integer(c_int64_t), allocatable, target :: bother(:,:)
+  real(c_double), allocatable, target :: bstate(:,:,:)
   integer(c_int32_t) :: magic, nsteps, mode
   integer(c_int64_t) :: n, n_slots, n_alive
   integer :: ni, nj, k, s, u
@@ -33,7 +44,8 @@ program kid_replay
 
   open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old', action='read')
   read(u) magic
-  if (magic /= 1263093761) error stop 'kid_replay: bad magic'
+  if (magic /= 1263093761 .and. magic /= 1263093762) error stop 'kid_replay: bad magic'
+  with_bonds = magic == 1263093762
   read(u) gd
   read(u) par
   read(u) nsteps, mode
@@ -48,6 +60,15 @@ program kid_replay
     read(u) bf(1:n,:)
     read(u) bi(1:n,:)
     read(u) bid(1:n)
+  end if
+  mb = 0
+  if (with_bonds) then
+    read(u) mb
+    allocate(bcount(n), bother(n, mb), bbroken(n, mb), bstate(n, mb, KID_NBOND_F64))
+    read(u) bcount
+    read(u) bother
+    read(u) bbroken
+    read(u) bstate
   end if
   close(u)
 
@@ -70,6 +91,14 @@ program kid_replay
   end do
   soa%id = c_loc(bid(1))
   call kid_check(kid_upload_bergs(h, soa), h, 'kid_upload_bergs')
+  if (with_bonds) then   ! the bond lists of the conglomerates (INTEGRATION.md section 4)
+    bsoa%n = n; bsoa%max_bonds = mb; bsoa%pad = 0
+    bsoa%count = c_loc(bcount(1)); bsoa%other_id = c_loc(bother(1,1)); bsoa%broken = c_loc(bbroken(1,1))
+    do k = 1, KID_NBOND_F64
+      bsoa%f64(k) = c_loc(bstate(1,1,k))
+    end do
+    call kid_check(kid_upload_bonds(h, bsoa), h, 'kid_upload_bonds')
+  end if
 
   ! the time loop of the driver (driver/icebergs_driver.F90:354-408); forcing is constant in the case file
   do s = 1, nsteps
@@ -92,6 +121,7 @@ program kid_replay
   call kid_check(kid_num_bergs(h, n_slots, n_alive), h, 'kid_num_bergs')
   soa%n = n_slots
   call kid_check(kid_download_bergs(h, soa), h, 'kid_download_bergs')
+  if (with_bonds) call kid_check(kid_download_bonds(h, bsoa), h, 'kid_download_bonds')
   allocate(acc(ni, nj, KID_NACC), outp(ni, nj, KID_NOUT), scal(KID_NSCALAR))
   call kid_check(kid_get_accumulators(h, c_loc(acc), c_loc(outp), c_loc(scal)), h, 'kid_get_accumulators')
   call kid_check(kid_destroy(h), h, 'kid_destroy')
@@ -106,6 +136,12 @@ program kid_replay
   write(u) acc
   write(u) outp
   write(u) scal
+  if (with_bonds) then
+    write(u) bcount
+    write(u) bother
+    write(u) bbroken
+    write(u) bstate
+  end if
   close(u)
   write(*,'(a,i0,a,i0,a,i0)') 'kid_replay: steps=', nsteps, ' bergs=', n_slots, ' alive=', n_alive
 end program kid_replay

@@ -352,3 +352,53 @@ def test_glue_lists_and_icebergs_run(oracle, tmp_path, staggers):
     key = list(zip(gb["jne"].tolist(), gb["ine"].tolist(), gb["start_year"].tolist(), gb["start_day"].tolist(), gb["start_mass"].tolist(),
                    gb["start_lon"].tolist(), gb["start_lat"].tolist()))
     assert key == sorted(key)
+
+
+def write_case_bonded(path, grid, p, b, bd, nsteps):
+    """the case file of kid_replay with a bonds section (magic + 1)"""
+    write_case(path, grid, p, b, nsteps, 0)
+    with open(path, "r+b") as f:
+        f.write(struct.pack("<i", MAGIC + 1))
+        f.seek(0, 2)
+        f.write(struct.pack("<i", bd["max_bonds"]))
+        f.write(bd["count"].astype(np.int32).tobytes())
+        f.write(bd["other_id"].astype(np.int64).tobytes())
+        f.write(bd["broken"].astype(np.int32).tobytes())
+        for name in T.BOND_F64_NAMES:
+            f.write(np.ascontiguousarray(bd[name], dtype=np.float64).tobytes())
+
+
+@pytest.mark.gpu
+def test_fortran_driver_bonded_cantilever_beam(oracle, tmp_path):
+    """The bonded path from the host language: the Fortran driver uploads the bergs and the bond lists of the reference's
+    cantilever-beam test (tests/dem_cbeam_test restated, 90 elements, tests/test_beam.py), steps it through kid_run_step --
+    which dispatches to the MTS / DEM path -- and downloads bergs and bonds.  40 of the test's 300 steps here (the whole run
+    against the analytic lines is test_beam.py's): the beam is bending, no bond has broken, and the state is bit for bit
+    what the same calls give from Python."""
+    grid, p, b, bd = S.config_beam("cantilever")
+    nsteps = 40
+    case, res = str(tmp_path / "beam.bin"), str(tmp_path / "beam.out")
+    write_case_bonded(case, grid, p, b, bd, nsteps)
+    r = subprocess.run([REPLAY, case, res], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bergs=90 alive=90" in r.stdout
+    gb, acc, out, scal = read_result(res, grid)
+    (pb, _, _, _), pbd = P.run_hip_mts(grid, p, b, bd, nsteps)
+    for f in ("lon", "lat", "uvel", "vvel", "rot", "ang_vel"):
+        assert np.array_equal(gb[f], pb[f]), f
+    tip = np.argmax(b["lon"] + 1e-3 * b["lat"])
+    assert gb["lat"][tip] - b["lat"][tip] < -20.0e3           # ~ -36 km after 40 steps, on its way to -48.7 km
+    n, mb = 90, bd["max_bonds"]
+    with open(res, "rb") as f:
+        d = grid["desc"]
+        ni, nj = d.ied - d.isd + 1, d.jed - d.jsd + 1
+        f.seek(8 + n * (8 * len(T.BERG_F64_NAMES) + 4 * len(T.BERG_I32_NAMES) + 8) + 8 * (T.NACC + T.NOUT) * ni * nj + 8 * T.NSCALAR)
+        count = np.frombuffer(f.read(4 * n), dtype=np.int32)
+        other = np.frombuffer(f.read(8 * n * mb), dtype=np.int64)
+        broken = np.frombuffer(f.read(4 * n * mb), dtype=np.int32)
+        length = np.frombuffer(f.read(8 * n * mb), dtype=np.float64)
+    assert np.array_equal(count, bd["count"]) and int(count.sum()) == 294
+    assert not broken.any()
+    live = (np.arange(mb)[:, None] < count[None, :]).ravel()
+    assert np.array_equal(other[live], bd["other_id"][live])
+    assert np.array_equal(length[live], pbd["length"][live])

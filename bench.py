@@ -242,6 +242,7 @@ def main():
                        "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) + %d scalars per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, T.NSCALAR, ", overlapped with the next step's kernels" if pipelined else "")) if multi else "none (1 GPU)",
                        "planes_reduced_per_step": (nreduced // ib.ncell) if multi else 0, "MB_reduced_per_step": (nreduced * 8 / 1e6) if multi else 0.0,
                        "bergs_alive_at_end": n_alive},
+            "library": ib.lib.kid_version().decode(),   # names the build switches (an experiment or exact-math build says so)
             "per_gpu_value": value / world, "host_submit_ms_per_step": 1e3 * t_submit / args.steps,
             "ms_per_step_rank_max": 1e3 * elapsed / args.steps, "ms_per_step_rank_min": 1e3 * elapsed_min / args.steps,
             # `bound` = the bound that binds the dominant kernel.  achieved / peak / frac are the HBM figures (algorithmic bytes over

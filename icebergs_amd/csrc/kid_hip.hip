@@ -386,6 +386,7 @@ struct kid_handle {
   int32_t *d_keep = nullptr;               // layout flags of such a run (keep_flags_kernel)
   long long mig_last[2] = {0, 0};          // records of the last pack call per slot: sizes the pinned staging buffer
   bool env_ever_stored = false;            // some launch since the last upload wrote berg%uo..od
+  bool env_off_requested = false;          // kid_set_store_environment(h, 0)
   double *d_orient = nullptr;              // bond-derived hexagon orientation per berg (mts / interacting bergs)
   hipEvent_t evF[2] = {nullptr, nullptr}, evG[2] = {nullptr, nullptr}; bool evG_live[2] = {false, false};
   // "slow lane" schedule (kid_set_side_stream mode 2, launch_berg_lanes)
@@ -719,7 +720,7 @@ int kid_set_params(kid_handle *h, const kid_params *params) {
   h->tables_dirty = true;
   h->labels_stale = true;   // (the conglomerate labelling reads dem / max_bonds / use_broken_bonds_for_substep_contact)
   h->flags.footprint = footprint_needed(h->params) ? 1 : 0;
-  if (!h->params.old_interp_flds_order) h->flags.store_env = 1;  // the stored environment is an input again
+  if (!h->params.old_interp_flds_order && !h->env_off_requested) h->flags.store_env = 1;  // the stored environment is an input again
   return KID_OK;
 }
 static int refresh_tables(kid_handle *h);
@@ -1161,10 +1162,15 @@ int kid_set_resort_interval(kid_handle *h, int steps) {
   return KID_OK;
 }
 
+// With .not.old_interp_flds_order the stored environment (berg%uo ... od) is an input of evolve_icebergs and thermodynamics as
+// the reference calls them, one after the other; the fused step (kid_run_step / kid_step_local) interpolates it for itself
+// and only writes it -- 104 B per berg-step that nothing inside the library reads back.  Switching the store off is
+// therefore allowed there too; the entry points that do read it then refuse to run (launch_berg) instead of reading values
+// of some earlier step.
 int kid_set_store_environment(kid_handle *h, int on) {
   if (!h) return KID_EINVAL;
-  if (!on && !h->params.old_interp_flds_order) { h->err = "the stored environment is an input unless old_interp_flds_order"; return KID_EINVAL; }
   h->flags.store_env = on ? 1 : 0;
+  h->env_off_requested = !on;
   return KID_OK;
 }
 
@@ -1198,6 +1204,10 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
   if (!h->have_forcing) { h->err = "kid_set_forcing must be called before stepping"; return KID_EINVAL; }
   if (h->n == 0 || range_len == 0) return KID_OK;
   const bool rk = h->params.Runge_not_Verlet != 0, old = h->params.old_interp_flds_order != 0;
+  if (!old && !(PH & PH_INTERP) && (PH & (PH_EVOLVE | PH_THERMO)) && !h->flags.store_env) {
+    h->err = "this entry point reads the bergs' stored environment, which kid_set_store_environment has switched off (use kid_run_step, or switch it on)";
+    return KID_EINVAL;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
 { int rc_t = lanes_drain(h); if (rc_t) return rc_t; }
 { int rc_t = refresh_tables(h); if (rc_t) return rc_t; }

@@ -92,8 +92,10 @@ int kid_set_resort_interval(kid_handle *h, int steps);
 
 /* berg%uo..od (the last interpolated environment).  With old_interp_flds_order accel re-interpolates (IB:2035) and the
  * stored copy is read only by trajectory records (FW:5422) and bergs_chksum (FW:7040): a run with ignore_traj=T may
- * switch it off (on = 0) and save 13 stores per berg per step.  Refused (KID_EINVAL at launch) when the stored
- * environment is an input, i.e. .not.old_interp_flds_order.  Default on. */
+ * switch it off (on = 0) and save 13 stores per berg per step.  With .not.old_interp_flds_order the stored environment is
+ * an input of evolve_icebergs and thermodynamics called one after the other, but not of the fused step, which interpolates
+ * it for itself: switched off there, kid_run_step / kid_step_local still run, and the entry points that read it
+ * (kid_evolve_icebergs, kid_thermodynamics) return KID_EINVAL.  Default on. */
 int kid_set_store_environment(kid_handle *h, int on);
 
 /* Forcing ingest on the device: the block of icebergs_run that builds grd%uo .. grd%hi from the

@@ -284,12 +284,27 @@ def test_store_environment_off(oracle):
             assert np.array_equal(ref[0][f][o1], got[f][o2]), f
         assert np.array_equal(acc, ref[1]) or P.rel_err(acc, ref[1]) < 1e-12
         assert np.all(got["uo"] == 123.0) and not np.all(ref[0]["uo"] == 123.0)
-        q = S.params_copy(p)
-        q.old_interp_flds_order = 0
-        q.Runge_not_Verlet = 0
-        ib.set_params(q)
+    finally:
+        ib.close()
+    # .not.old_interp_flds_order: the stored environment is an input of the phase-by-phase entry points, not of the fused step
+    q = S.params_copy(p)
+    q.old_interp_flds_order, q.Runge_not_Verlet, q.use_new_predictive_corrective = 0, 0, 1
+    ref = P.run_hip(grid, q, b, 6)
+    ib = Icebergs(grid, q, capacity=len(b["lon"]), device=0)
+    try:
+        ib.upload_bergs(b)
+        ib.set_store_environment(False)
+        ib.run(6)
+        acc, out, scal = ib.fetch()
+        got = ib.download_bergs()
+        o1, o2 = np.argsort(ref[0]["id"]), np.argsort(got["id"])
+        for f in P.TRAJ_FIELDS + P.SIZE_FIELDS:
+            assert np.array_equal(ref[0][f][o1], got[f][o2]), f
+        assert np.array_equal(acc, ref[1]) or P.rel_err(acc, ref[1]) < 1e-12
+        assert np.all(got["uo"] == 123.0) and not np.all(ref[0]["uo"] == 123.0)
         with pytest.raises(KidError):
-            ib.set_store_environment(False)
+            ib.run_phases(1)     # kid_evolve_icebergs reads the stored environment
+        ib.set_store_environment(True)
     finally:
         ib.close()
 

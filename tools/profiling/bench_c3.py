@@ -13,6 +13,8 @@ print("generated %d bergs in %.1f s" % (n, time.time() - t0), flush=True)
 cap = len(b["lon"])
 ib = Icebergs(grid, p, capacity=cap, device=0)
 ib.upload_bergs(b)
+if os.environ.get("KID_C3_NO_ENV_STORE"):   # the fused step does not read the stored environment back: 104 B per berg-step less to write
+    ib.set_store_environment(False)
 ib.run(2); ib.sync()
 t0 = time.time()
 ib.run(steps); ib.sync()

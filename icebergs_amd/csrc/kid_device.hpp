@@ -226,6 +226,7 @@ struct PkCell {
   __device__ __forceinline__ double area() const { return pk[PK_AREA]; }
   __device__ __forceinline__ double msk(int di, int dj) const { return pk[PK_MSK + (di + 1) + 3 * (dj + 1)]; }
   __device__ __forceinline__ bool hotok() const { return pk[PK_HOTOK] != 0.; }
+  __device__ __forceinline__ bool rect() const { return pk[PK_HOTOK] == 2.; }   // sides along the axes (pack_static_kernel)
 };
 template <bool FAST> struct CellOf;
 template <> struct CellOf<true> {
@@ -423,6 +424,14 @@ __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_para
       const double x1 = q.lon11 - (ddx / 2), y1 = q.lat11 - (ddy / 2);
       xi = kid_div(mod_around(x, x1, g.Lx) - x1, ddx) + 0.5;
       yj = kid_div(y - y1, ddy) + 0.5;
+    } else if (cell.rect()) {
+      // calc_xiyj on a cell whose sides lie along the axes: beta, delta, gamma, kappa and the quadratic coefficient are exact
+      // zeros, and what is left of its linear branch is this -- the same operations on the same values, bit for bit
+      const double alpha = q.lon10 - q.lon00, epsilon = q.lat01 - q.lat00;
+      const double dx = mod_around(x, q.lon00, g.Lx) - q.lon00, dy = y - q.lat00;
+      const double b = -(alpha * epsilon), c = alpha * dy;
+      yj = (b != 0.) ? kid_div(-c, b) : 0.;
+      if (alpha != 0.) xi = kid_div(dx, alpha); else { err = 1; xi = -999.; }
     } else if (!calc_xiyj(q.lon00, q.lon10, q.lon11, q.lon01, q.lat00, q.lat10, q.lat11, q.lat01, x, y, xi, yj, g.Lx)) err = 1;
     const bool inside = (dmin(xi, yj) > HOT_EDGE) && (dmax(xi, yj) < 1. - HOT_EDGE);
     if (!inside) bail = true;

@@ -60,7 +60,11 @@ __global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec 
     const double k2 = (x3 - x2) * (y0 - y3) - (y3 - y2) * (x0 - x3), k3 = (x0 - x3) * (y1 - y0) - (y0 - y3) * (x1 - x0);
     const bool convex = (k0 > 0. && k1 > 0. && k2 > 0. && k3 > 0.) || (k0 < 0. && k1 < 0. && k2 < 0. && k3 < 0.);
     const bool polar = latlon && dmax(dmax(y0, y1), dmax(y2, y3)) >= 89.999;
-    if (convex && !polar) ok = 1.;
+    // 2: moreover its sides lie along the axes as calc_xiyj sees the corners (beta = delta = gamma = kappa = 0 there: its
+    // linear branch, with xi = dx / alpha), the cell of every regular lat-lon grid -- the hot build takes that branch directly
+    const double *lo = gp.st[KID_G_LON];
+    const bool rect = lo[c - 1] == lo[c - ni - 1] && lo[c] == lo[c - ni] && lat[c - ni] == lat[c - ni - 1] && lat[c] == lat[c - 1];
+    if (convex && !polar) ok = rect ? 2. : 1.;
   }
   hotok[c] = ok;
 }

@@ -54,7 +54,9 @@ def cases():
     def sts_kid_contact():
         g, p, b, bd = S.config_c4(bump=(150e3, 150e3), dem=False, mts=False, contact=True, spring_coef=1e-5, dt=60.0, two_bergs=True, hexagonal=False, nx=4, ny=6)
         S.set_diag_all(p); return g, p, b, bd
-    extra = {"c4_kid_implicit": (c4_kid_implicit, 6), "sts_kid_contact": (sts_kid_contact, 100)}
+    def c4_beam_cantilever():   # the reference's dem_cbeam_test population (tests/test_beam.py): static elements, only_interactive_forces, the end load
+        g, p, b, bd = S.config_beam("cantilever"); S.set_diag_all(p); return g, p, b, bd
+    extra = {"c4_kid_implicit": (c4_kid_implicit, 6), "sts_kid_contact": (sts_kid_contact, 100), "c4_beam_cantilever": (c4_beam_cantilever, 4)}
     base = _base(c1_rk4, c1_verlet, c2_small, c3_fl_bits, c3_new_bergs, c4_hex_grounded, c4_two_bergs)
     base.update(extra)
     return base
@@ -94,7 +96,7 @@ def run_case(name):
 
 
 def main():
-    for name in cases():
+    for name in (sys.argv[1:] or cases()):
         res = run_case(name)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **res)

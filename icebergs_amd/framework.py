@@ -5,7 +5,9 @@ Fortran binding lives in icebergs_amd/fortran/.  This module is the same thin ho
 the tests, bench.py and the multi-GPU driver: it owns no numerics, it only moves arrays across the C ABI
 (include/kid.h) and calls the phases in the order icebergs_run does (IB:5423-5512).
 """
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -15,6 +17,21 @@ from . import types as T
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_handles():
+    """Handles still open when the interpreter exits are destroyed here, while the HIP runtime (and a profiler attached to it)
+    is still up: a handle left to `__del__` during interpreter shutdown -- or never finalised at all -- used to keep its
+    streams, captured graphs and the cooperative launch's buffers alive into the runtime's own exit handlers."""
+    for ib in list(_LIVE):
+        try:
+            ib.close()
+        except Exception:
+            pass
 
 
 class Icebergs:
@@ -49,6 +66,7 @@ class Icebergs:
         self.acc = np.zeros((T.NACC, self.nj, self.ni))
         self.out = np.zeros((T.NOUT, self.nj, self.ni))
         self.scalars = np.zeros(T.NSCALAR)
+        _LIVE.add(self)
 
     def _check(self, rc, what):
         if rc != 0:
@@ -58,6 +76,7 @@ class Icebergs:
         if getattr(self, "h", None):
             self.lib.kid_destroy(self.h)
             self.h = None
+        _LIVE.discard(self)
 
     def __del__(self):
         try:

@@ -1,15 +1,16 @@
-"""bergs_chksum (icebergs_framework.F90:6889-6987) on the structure of arrays, and the reference-held numbers it gives access to.
+"""bergs_chksum (icebergs_framework.F90:6889-6987) on the structure of arrays: the routine itself.
 
 The reference's regression tests record one line per run, "chksum=.. chksum2=.. chksum3=.. chksum4=.. chksum5=.. #=..", printed by
-bergs_chksum at icebergs_save_restart (tests/collision_tests/README:13-22, tests/dem_ground_frac_test/input.nml:7-10,
-tests/footloose_tests/input.nml:1, tests/a68_test/long_run.nml:1-2).  chksum..chksum4 are sums of IEEE bit patterns of
-positions, velocities and sizes after a long run of a binary built with another compiler: they cannot be reproduced by any
-other implementation, this one included.  What is comparable is held here:
-  * '#', the number of bergs at the end of the run (69 for tests/dem_ground_frac_test, whose generator is restated in
-    icebergs_amd/synthetic.py:dem_ground_frac_elements), and chksum5 = 0 in every recorded line, which follows from the
-    routine's own structure (its per-cell sum starts over in every cell and the last cell of the domain is empty);
-  * the routine itself, restated three times independently -- numpy below, the CPU oracle (ko_bergs_chksum) and the HIP
-    library's host side (kid_bergs_chksum) -- must give identical integers on identical states.
+bergs_chksum at icebergs_save_restart (tests/collision_tests/README:13-22, the head of every tests/*/input*.nml).  Which of those
+integers are reachable, and the tests that reproduce them (chksum3 = chksum4 and '#': functions of log(mass) and of the final
+per-cell occupancy only), are in tests/test_reference_chksums.py.  chksum / chksum2 (bit patterns of the positions, velocities
+and sizes of the bergs of the LAST occupied cell, out of another compiler's binary) and chksum5 (berg_chksum of the bergs in each
+PE's last cell: 0 in most recorded lines, -81885495 / -845603363 in tests/dem_cbeam_test/input.nml:2,5 where the bent beam
+crosses the last cell of a PE of the 4-PE run) depend on bit patterns of positions and stay out of reach.
+Held here:
+  * the routine, restated three times independently -- numpy below, the CPU oracle (ko_bergs_chksum) and the HIP library's host
+    side (kid_bergs_chksum) -- must give identical integers on identical states;
+  * its structure: the per-cell sum chksum5 starts over in every cell, so on one PE it is 0 whenever the last cell is empty.
 """
 import numpy as np
 import pytest

@@ -13,3 +13,4 @@ ib.upload_bergs(b); ib.upload_bonds(bd)
 ib.run(1); ib.sync()
 t0 = time.time(); ib.run(nsteps); ib.sync(); dt = time.time() - t0
 print("%s: %d steps x %d sub-steps: %.1f ms/step, %.2f us per sub-step" % (kind, nsteps, p.mts_sub_steps, 1e3 * dt / nsteps, 1e6 * dt / nsteps / p.mts_sub_steps))
+ib.close()

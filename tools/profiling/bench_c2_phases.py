@@ -9,3 +9,4 @@ ib.upload_bergs(b); ib.set_store_environment(False)
 ib.run_phases(3); ib.sync()
 t0 = time.time(); ib.run_phases(20); ib.sync(); print("phases: %.3f ms/step" % (1e3 * (time.time() - t0) / 20))
 t0 = time.time(); ib.run(20); ib.sync(); print("fused: %.3f ms/step" % (1e3 * (time.time() - t0) / 20))
+ib.close()

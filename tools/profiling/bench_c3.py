@@ -22,3 +22,4 @@ dt = time.time() - t0
 print("steps %d: %.3f ms/step, %.3e berg-steps/s" % (steps, 1e3 * dt / steps, n * steps / dt), flush=True)
 acc, out, scal = ib.fetch()
 print("scalars", scal, "n_slots", ib.num_bergs())
+ib.close()

@@ -25,3 +25,4 @@ if len(sys.argv) > 3:
     import oracle_lib
     o = oracle_lib.Oracle(grid, p)
     t0 = time.time(); o.run_step_mts(b, bd, 1); print("oracle 1 step: %.2f s" % (time.time() - t0))
+ib.close()

@@ -46,3 +46,4 @@ ncell = ib.ni * ib.nj
 nbytes = 8 * ncell * (2 + 3 + 2 * 2 + 2 * T.ENUMS["KID_NCLASSES"] + 2 * T.ENUMS["KID_NCLASSES"])   # inputs, static, planes r+w, buckets r+w twice
 print(json.dumps({"what": "kid_calving", "grid": [a.ni, a.nj], "calving_cells": int((calv > 0).sum()), "us_per_call": round(us, 1),
                   "bergs_calved_per_call": round((n1 - n0) / a.iters, 1), "plane_traffic_MB": round(nbytes / 1e6, 1)}))
+ib.close()

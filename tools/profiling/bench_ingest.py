@@ -45,3 +45,4 @@ nbytes = 8 * (sum(int(np.prod(v.shape)) for v in args.values()) + ncell         
               + T.ENUMS["KID_NFORCING"] * ncell * 3 + 2 * ncell)                  # planes: written, scrubbed (read + write); ua/va read
 print(json.dumps({"what": "kid_ingest_forcing + per-cell record pack", "grid": [a.ni, a.nj], "vel": a.vel, "stress": a.stress,
                   "us_per_call": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2), "GB_per_s": round(nbytes / us / 1e3, 1)}))
+ib.close()

@@ -71,3 +71,4 @@ for it in range(a.iters + 2):
 print(json.dumps({"what": "kid_pack_emigrants x4 + kid_unpack_immigrants x4", "bergs": a.bergs, "records_per_step": packed // a.iters,
                   "pack_us_per_step": round(t_pack * 1e6 / a.iters, 1), "unpack_us_per_step": round(t_unpack * 1e6 / a.iters, 1),
                   "pair_pack_us_per_step": round(t_pack2 * 1e6 / a.iters, 1), "pair_unpack_us_per_step": round(t_unpack2 * 1e6 / a.iters, 1)}))
+ib.close()

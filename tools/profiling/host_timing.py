@@ -34,3 +34,4 @@ s2 = torch.cuda.Stream(dev)
 def ctx():
     with torch.cuda.stream(s2): pass
 timeit("torch stream ctx", ctx)
+ib.close()

@@ -76,3 +76,4 @@ d = grid["desc"]
 assert (got["ine"][live] >= d.isc).all() and (got["ine"][live] <= d.iec).all()
 assert np.isfinite(out).all() and np.isfinite(acc).all()
 print("soak ok (%s): %d steps, %d alive, %d calved, %d melted, %d left the domain, checksum %.6e, %.1f s" % ("plain" if plain else "slow lane", nsteps, int(live.sum()), calved, melted, left, float(np.sort(got["mass"][live]).sum()), time.time() - t0))
+ib.close()

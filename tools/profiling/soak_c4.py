@@ -20,6 +20,7 @@ if os.environ.get("KID_SOAK_CHILD"):
     o = np.argsort(g["id"])
     np.savez(os.environ["KID_SOAK_CHILD"], lon=g["lon"][o], lat=g["lat"][o], uvel=g["uvel"][o], rot=g["rot"][o], conglom=g["conglom_id"][o], scal=scal,
              broken=int((gb["broken"] != 0).sum()), nbonds=int(gb["count"].sum()))
+    ib.close()
     sys.exit(0)
 res = {}
 for name, env in (("fused", {}), ("graph", {"KID_MTS_NO_FUSED": "1"})):

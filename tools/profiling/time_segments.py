@@ -24,3 +24,4 @@ tot = sum(out[1 + q] for q in range(11))
 print("waves %d (hot + general builds), cycles per wave %.0f" % (out[0], tot / max(out[0], 1)))
 for q, nm in enumerate(names):
     print("%-34s %5.1f %%" % (nm, 100.0 * out[1 + q] / tot))
+ib.close()

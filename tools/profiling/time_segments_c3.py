@@ -20,3 +20,4 @@ tot = sum(out[1 + q] for q in range(11))
 print("waves %d, cycles per wave %.0f" % (out[0], tot / max(out[0], 1)))
 for q, nm in enumerate(names):
     if out[1 + q]: print("%-80s %5.1f %%" % (nm, 100.0 * out[1 + q] / tot))
+ib.close()

@@ -22,3 +22,4 @@ tot = sum(out[1 + q] for q in range(4))
 print("waves %d, cycles per wave and sub-step %.0f" % (out[0], tot / max(out[0], 1) / p.mts_sub_steps))
 for q, nm in enumerate(names):
     print("%-46s %5.1f %%" % (nm, 100.0 * out[1 + q] / tot))
+ib.close()

@@ -50,6 +50,11 @@ template <int K> struct Fl {
 //                A berg that meets anything else is left untouched and its index is appended to `redo`.
 //   FAST=false : the general code (cell hops, coast bounce, polar cells, tangent plane) over the `redo` list.
 // Keeping the rare branches out of the hot build roughly halves its register footprint (2 waves/SIMD, no scratch).
+// Threads per workgroup of the hot build.  A workgroup's LDS and registers are released when its LAST wave ends: with four
+// waves per workgroup a SIMD slot whose wave finished early (few runs, no bails) idles until the slowest of the four is done.
+#ifndef KID_HOT_WG
+#define KID_HOT_WG 256
+#endif
 #ifndef KID_GENERAL_WAVES_PER_EU
 #define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
 #endif
@@ -64,7 +69,7 @@ struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;   
 #define KID_NUM_VGPR_ATTR
 #endif
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K = 0>
-__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid *__restrict__ gtab, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
+__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid *__restrict__ gtab, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
                                                    double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
   // The parameter block (142 dwords) and the 51 field pointers are read through device-memory tables on demand:
   // as by-value kernel arguments they were all pinned in SGPRs, overflowed the scalar file and came back as
@@ -73,12 +78,13 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(256, FAST ? KID_WAVES_PER_EU
   const BergPtrs &b = *bt;
   const DevGrid &g = *gtab;   // like the other two tables: read on demand, not pinned in ~50 SGPRs for the whole kernel
   constexpr bool SCATTER = (PH & (PH_THERMO | PH_SPREAD)) != 0;
-  __shared__ double lds_vals[SCATTER ? KID_SEG_LDS_DOUBLES : 1];   // staging of the per-cell sums (kid_thermo.hpp)
-  __shared__ int lds_ints[KID_SEG_LDS_INTS];                         // run tables of the 4 waves
-  __shared__ double lds_pk[FAST ? 4 * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the 4 waves (hot build)
+  constexpr int WG_WAVES = FAST ? KID_HOT_WG / 64 : 4;   // (the general build is launched one wave per workgroup; its other entry points with up to four)
+  __shared__ double lds_vals[SCATTER ? seg_lds_doubles(WG_WAVES) : 1];   // staging of the per-cell sums (kid_thermo.hpp)
+  __shared__ int lds_ints[seg_lds_ints(WG_WAVES)];                         // run tables of the workgroup's waves
+  __shared__ double lds_pk[FAST ? WG_WAVES * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the workgroup's waves (hot build)
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
   const long long total = FAST ? redo.klen : (long long)(*redo.count);
-  const long long bdim = FAST ? 256ll : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
+  const long long bdim = FAST ? (long long)KID_HOT_WG : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
   // (the hot build's "loop" visibly runs once: otherwise the compiler hoists the constants of the whole body out of it and
   // holds -- or spills -- them in vector registers)
   long long tid = (long long)blockIdx.x * bdim + threadIdx.x;

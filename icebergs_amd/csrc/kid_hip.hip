@@ -1230,7 +1230,7 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
   for (int part = 0; part < nparts; ++part) {
     const long long k0 = (nparts == 1) ? range_k0 : (part == 0 ? 0 : half);
     const long long klen = (nparts == 1) ? (range_len < 0 ? h->n : range_len) : (part == 0 ? half : h->n - half);
-    const unsigned nbp = (unsigned)((klen + 255) / 256);
+    const unsigned nbp = (unsigned)((klen + KID_HOT_WG - 1) / KID_HOT_WG);
     const Redo redo{part == 0 ? h->d_redo_list : h->d_redo_list2, h->d_redo_cnt[part][h->redo_parity], k0, klen, nullptr, 0,
                     h->d_fl_cursor, h->d_iceberg_counter, (long long)h->capacity, h->gd.iec - h->gd.isc + 1, h->fl_step};
     hipStream_t gs = (nparts == 2) ? h->side_stream : h->stream;
@@ -1244,12 +1244,12 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
     if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                       \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(256), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     else                                                                                                                        \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \
     if (nparts == 2) { (void)hipEventRecord(h->evF[part], h->stream); (void)hipStreamWaitEvent(gs, h->evF[part], 0); }          \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3(4u * nbp < 2048u ? 4u * nbp : 2048u), dim3(64), 0, gs, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, false>), dim3((unsigned)std::min<long long>((klen + 63) / 64, 2048)), dim3(64), 0, gs, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo); \
     if (nparts == 2) { (void)hipEventRecord(h->evG[part], gs); h->evG_live[part] = true; } else h->evG_live[part] = false;      \
   } while (0)
     if (rk && old) KID_LAUNCH(true, true);
@@ -1298,7 +1298,7 @@ static int launch_berg_lanes(kid_handle *h) {
   int *list_new = par ? h->d_redo_list2 : h->d_redo_list, *list_old = par ? h->d_redo_list : h->d_redo_list2;
   const Redo hot{list_new, h->d_redo_cnt[0][par], 0, h->n, h->d_lane, s};
   const Redo carry{list_old, h->d_redo_cnt[0][par ^ 1], 0, h->n, nullptr, 0};
-  const unsigned nbp = (unsigned)((h->n + 255) / 256), nbg = 4u * nbp < 2048u ? 4u * nbp : 2048u;
+  const unsigned nbp = (unsigned)((h->n + KID_HOT_WG - 1) / KID_HOT_WG), nbg = (unsigned)std::min<long long>((h->n + 63) / 64, 2048);
   // Every record / wait is a barrier packet of ~5 us on the stream it goes to: the main stream gets one wait (in the
   // prepass) and two records per step; with profiling on, the (start, stop) pair of the hot build doubles as the two.
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1314,9 +1314,9 @@ static int launch_berg_lanes(kid_handle *h) {
        before last included) is complete once the next prepass has waited for it */                                          \
     (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
     if (RKV && OLDV && plain)                                                                                                   \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     else                                                                                                                        \
-    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(256), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(evF, M);                                                                                               \
     if (h->profile) { h->pending.emplace_back(e0, e1); h->berg_launches++; }                                                    \
     if (rebin_now) {                                                                                                            \

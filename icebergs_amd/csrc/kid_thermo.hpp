@@ -46,9 +46,9 @@ struct Seg {
   unsigned M;        // ceil(65536 / R): item / R == (item * M) >> 16 for item < 1024
   int npend;         // staged slots (wave-uniform)
 };
-// LDS a workgroup of 4 waves needs for its Seg tables
-constexpr int KID_SEG_LDS_DOUBLES = 4 * KID_CHUNK * KID_ROW + 4;
-constexpr int KID_SEG_LDS_INTS = 4 * (3 * 64 + KID_CHUNK);
+// LDS a workgroup of `waves` waves needs for its Seg tables
+constexpr int seg_lds_doubles(int waves) { return waves * KID_CHUNK * KID_ROW + 4; }
+constexpr int seg_lds_ints(int waves) { return waves * (3 * 64 + KID_CHUNK); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -39,6 +39,14 @@ def build(verbose=False):
     return SO_PATH
 
 
+def device_reset():
+    """hipDeviceReset() through the HIP runtime the process already holds.  For stand-alone scripts that end under a profiler:
+    a process that has run a cooperative launch (the fused MTS sub-step kernel) and exits under rocprofv3 faults inside the
+    runtime's own exit handlers, after the tool has finalised -- with every handle closed as well; resetting the device while
+    everything is still up avoids relying on that exit order.  Never called by the library itself."""
+    C.CDLL("libamdhip64.so").hipDeviceReset()
+
+
 _lib = None
 
 

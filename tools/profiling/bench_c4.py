@@ -26,3 +26,7 @@ if len(sys.argv) > 3:
     o = oracle_lib.Oracle(grid, p)
     t0 = time.time(); o.run_step_mts(b, bd, 1); print("oracle 1 step: %.2f s" % (time.time() - t0))
 ib.close()
+if os.environ.get("KID_DUMP_MAPS"):   # which libraries sit where (to read a native stack trace of the exit path)
+    open(os.environ["KID_DUMP_MAPS"], "w").write("".join(l for l in open("/proc/self/maps") if " r-xp " in l))
+from icebergs_amd import lib as _kl
+_kl.device_reset()   # see lib.device_reset: exit order under rocprofv3 after a cooperative launch

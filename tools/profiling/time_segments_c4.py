@@ -23,3 +23,5 @@ print("waves %d, cycles per wave and sub-step %.0f" % (out[0], tot / max(out[0],
 for q, nm in enumerate(names):
     print("%-46s %5.1f %%" % (nm, 100.0 * out[1 + q] / tot))
 ib.close()
+from icebergs_amd import lib as _kl
+_kl.device_reset()   # see lib.device_reset: exit order under rocprofv3 after a cooperative launch

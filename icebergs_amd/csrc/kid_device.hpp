@@ -104,6 +104,15 @@ __device__ __forceinline__ double kid_div(double a, double b) {  // one more cor
   return __builtin_fma(__builtin_fma(-b, q, a), r.r, q);
 }
 #endif
+// kid_div(a, b) with the refined reciprocal of b already in hand (a divisor that repeats: the same bits as kid_div)
+#ifdef KID_EXACT_MATH
+__device__ __forceinline__ double kid_div_r(double a, double b, Rcp) { return a / b; }
+#else
+__device__ __forceinline__ double kid_div_r(double a, double b, Rcp r) {
+  const double q = a * r.r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r.r, q);
+}
+#endif
 // a*b + c.  The library is compiled with -ffp-contract=off and stays so: left to the compiler, contraction differs between
 // the hot and the general build of the same source line, and a berg's result would depend on which of them stepped it.
 // Where the hot loop spends its multiplies and adds (bilinear interpolation, rotations, sums of squares) the fused form is
@@ -126,6 +135,21 @@ __device__ __forceinline__ double kid_sqrt(double x) {
   g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
   g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
   return (x > 0.) ? g : ((x == 0.) ? x : __builtin_nan(""));
+}
+#endif
+
+// The same for a sum of squares of speeds (never negative, never infinite): the seed is taken of max(x, 1e-300), so x = 0 comes
+// out as 0 through the arithmetic itself (g = 0 * 1e150 = 0 in every step) and the three selects of the general form go; the
+// result is the same bits as kid_sqrt(x) for every x that is 0 or >= 1e-300.
+#ifdef KID_EXACT_MATH
+__device__ __forceinline__ double kid_sqrt_nn(double x) { return sqrt(x); }
+#else
+__device__ __forceinline__ double kid_sqrt_nn(double x) {
+  const double y = __builtin_amdgcn_rsq(__builtin_fmax(x, 1.e-300));
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  return __builtin_fma(__builtin_fma(-g, g, x), h, g);
 }
 #endif
 
@@ -212,6 +236,9 @@ struct GlbCell {
   __device__ __forceinline__ double ddy(int k) const { return g.trc[c + (1 - (k % 3)) - (k / 3) * g.ni].ddy; }
   __device__ __forceinline__ double area() const { return g.geo[c].area; }
   __device__ __forceinline__ double msk(int di, int dj) const { return g.geo[c + di + dj * g.ni].msk; }
+  __device__ __forceinline__ bool unrot() const {
+    return vel(0, 0) == 1. && vel(1, 0) == 1. && vel(2, 0) == 1. && vel(3, 0) == 1. && vel(0, 1) == 0. && vel(1, 1) == 0. && vel(2, 1) == 0. && vel(3, 1) == 0.;
+  }
 };
 struct PkCell {
   const lds_double *pk;
@@ -225,8 +252,12 @@ struct PkCell {
   __device__ __forceinline__ double ddy(int k) const { return pk[PK_DDY + k]; }
   __device__ __forceinline__ double area() const { return pk[PK_AREA]; }
   __device__ __forceinline__ double msk(int di, int dj) const { return pk[PK_MSK + (di + 1) + 3 * (dj + 1)]; }
-  __device__ __forceinline__ bool hotok() const { return pk[PK_HOTOK] != 0.; }
-  __device__ __forceinline__ bool rect() const { return pk[PK_HOTOK] == 2.; }   // sides along the axes (pack_static_kernel)
+  // PK_HOTOK holds +-(1 + 2 [sides along the axes, pack_static_kernel] + 4 [unrotated: cos = 1 and sin = 0 at the four corners]),
+  // positive where the hot build may step a berg of the cell: DevGrid::hotok and no NaN among the sea-surface-slope stencil
+  // values (pack_packets_kernel), so that the hot evolve needs no NaN test of its own (IB:4869-4870); 0 on the data domain's rim
+  __device__ __forceinline__ bool hotok() const { return pk[PK_HOTOK] > 0.; }
+  __device__ __forceinline__ bool rect() const { const double f = pk[PK_HOTOK]; return f == 3. || f == 7.; }
+  __device__ __forceinline__ bool unrot() const { return fabs(pk[PK_HOTOK]) >= 5.; }
 };
 template <bool FAST> struct CellOf;
 template <> struct CellOf<true> {
@@ -414,9 +445,20 @@ __device__ __noinline__ void pos_within_polar_cell(const DevGrid &g, const kid_p
 // A berg of the hot build sits in a cell with hotok = 1 (checked once per step), so "in the cell" is "(xi, yj) in the unit
 // square"; within HOT_EDGE of an edge, where rounding could make the two tests differ, the berg goes to the general build.
 constexpr double HOT_EDGE = 1.e-8;
-template <bool FAST, int K = 0, class CELL>
+// A berg of the hot build searches the same cell five times a step; for a cell with sides along the axes the two divisors of
+// that search (alpha = the cell's width, b = -alpha * its height) are inverted once (the same refined reciprocals kid_div
+// would form each time: the same bits).
+struct RectInv { double alpha, b; Rcp ra, rb; };
+__device__ __forceinline__ RectInv rect_inv(const Corners &q) {
+  RectInv r;
+  r.alpha = q.lon10 - q.lon00;
+  r.b = -(r.alpha * (q.lat01 - q.lat00));
+  r.ra = kid_rcp(r.alpha); r.rb = kid_rcp(r.b);
+  return r;
+}
+template <bool FAST, int K = 0, bool HAVE_RI = false, class CELL>
 __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_params &p, const CELL &cell, double x, double y, int i, int j,
-                                                double &xi, double &yj, int &err, bool &bail) {
+                                                double &xi, double &yj, int &err, bool &bail, const RectInv ri = RectInv{}) {
   if constexpr (FAST) {
     const Corners q = cell.corners();
     if (!grid_latlon<K>(g) && g.regular) {
@@ -427,11 +469,17 @@ __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_para
     } else if (cell.rect()) {
       // calc_xiyj on a cell whose sides lie along the axes: beta, delta, gamma, kappa and the quadratic coefficient are exact
       // zeros, and what is left of its linear branch is this -- the same operations on the same values, bit for bit
-      const double alpha = q.lon10 - q.lon00, epsilon = q.lat01 - q.lat00;
       const double dx = mod_around(x, q.lon00, g.Lx) - q.lon00, dy = y - q.lat00;
-      const double b = -(alpha * epsilon), c = alpha * dy;
-      yj = (b != 0.) ? kid_div(-c, b) : 0.;
-      if (alpha != 0.) xi = kid_div(dx, alpha); else { err = 1; xi = -999.; }
+      if constexpr (HAVE_RI) {
+        const double c = ri.alpha * dy;
+        yj = (ri.b != 0.) ? kid_div_r(-c, ri.b, ri.rb) : 0.;
+        if (ri.alpha != 0.) xi = kid_div_r(dx, ri.alpha, ri.ra); else { err = 1; xi = -999.; }
+      } else {
+        const double alpha = q.lon10 - q.lon00, epsilon = q.lat01 - q.lat00;
+        const double b = -(alpha * epsilon), c = alpha * dy;
+        yj = (b != 0.) ? kid_div(-c, b) : 0.;
+        if (alpha != 0.) xi = kid_div(dx, alpha); else { err = 1; xi = -999.; }
+      }
     } else if (!calc_xiyj(q.lon00, q.lon10, q.lon11, q.lon01, q.lat00, q.lat10, q.lat11, q.lat01, x, y, xi, yj, g.Lx)) err = 1;
     const bool inside = (dmin(xi, yj) > HOT_EDGE) && (dmax(xi, yj) < 1. - HOT_EDGE);
     if (!inside) bail = true;
@@ -473,13 +521,25 @@ __device__ __forceinline__ void bilin_lonlat(const DevGrid &g, const kid_params 
 // ---------------------------------------------------------------------------------------------------------
 // need_ice = false (wave-uniform): no berg of the wave sits in a cell with sea ice (hi = 0: c_ice = 0, IB:2129), so the ice
 // velocity multiplies 0 wherever it goes and is not interpolated -- bitwise the same accelerations
-template <int K = 0, class CELL>
+// NANFREE: the caller has checked that the cell's stencil values hold no NaN (hot evolve: PkCell::hotok)
+template <int K = 0, bool NANFREE = false, class CELL>
 __device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cell, double xi, double yj, Env &e, bool need_ice = true) {
   double wx1, wx0, wy1, wy0;  // weights of columns i / i-1 and rows j / j-1 (FW:7081-7087)
   if (Sw<K>::old_bug_bilin(p)) { wx1 = 1. - xi; wx0 = xi; wy1 = 1. - yj; wy0 = yj; }
   else { wx1 = xi; wx0 = 1. - xi; wy1 = yj; wy0 = 1. - yj; }
 #define KID_BIL(f) kid_fma(kid_fma(cell.vel(3, f), wx1, cell.vel(2, f) * wx0), wy1, kid_fma(cell.vel(1, f), wx1, cell.vel(0, f) * wx0) * wy0)
-  const double cos_rot = KID_BIL(0), sin_rot = KID_BIL(1);
+  // A cell whose four corners carry cos = 1, sin = 0 (every cell of an unrotated grid; elsewhere all but the displaced-pole
+  // patches) is not rotated at all: the reference interpolates cos to 1 or 1 - 2^-53 (the weights' own rounding) and multiplies
+  // by it; here such a cell's velocities pass through, in both builds alike (a per-cell property: the result does not depend on
+  // which other bergs share the wave).  -DKID_EXACT_MATH keeps the interpolated rotation.
+#ifdef KID_EXACT_MATH
+  const bool unrot = false;
+#else
+  const bool unrot = cell.unrot();
+#endif
+  const bool all_unrot = __ballot(!unrot) == 0ull;   // wave-uniform: nothing to rotate in this wave
+  double cos_rot = 1., sin_rot = 0.;
+  if (!all_unrot) { cos_rot = KID_BIL(0); sin_rot = KID_BIL(1); }
   double uo = KID_BIL(2), vo = KID_BIL(3), ui = 0., vi = 0., ua = KID_BIL(6), va = KID_BIL(7);
   if (need_ice) { ui = KID_BIL(4); vi = KID_BIL(5); }
 #undef KID_BIL
@@ -510,13 +570,17 @@ __device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cel
   }
   double ssh_y = kid_fma(yj, hxp, (1. - yj) * hxm);
   // rotate to lat-lon (IB:4953-4967)
-  double t;
-  t = uo; uo = kid_fma(cos_rot, t, sin_rot * vo); vo = kid_fma(cos_rot, vo, -(sin_rot * t));
-  if (need_ice) { t = ui; ui = kid_fma(cos_rot, t, sin_rot * vi); vi = kid_fma(cos_rot, vi, -(sin_rot * t)); }
-  t = ua; ua = kid_fma(cos_rot, t, sin_rot * va); va = kid_fma(cos_rot, va, -(sin_rot * t));
-  t = ssh_x; ssh_x = kid_fma(cos_rot, t, sin_rot * ssh_y); ssh_y = kid_fma(cos_rot, ssh_y, -(sin_rot * t));
-  if (ssh_x != ssh_x) ssh_x = 0.;
-  if (ssh_y != ssh_y) ssh_y = 0.;
+  if (!all_unrot) {
+    double t, r0, r1;
+    t = uo; r0 = kid_fma(cos_rot, t, sin_rot * vo); r1 = kid_fma(cos_rot, vo, -(sin_rot * t)); if (!unrot) { uo = r0; vo = r1; }
+    if (need_ice) { t = ui; r0 = kid_fma(cos_rot, t, sin_rot * vi); r1 = kid_fma(cos_rot, vi, -(sin_rot * t)); if (!unrot) { ui = r0; vi = r1; } }
+    t = ua; r0 = kid_fma(cos_rot, t, sin_rot * va); r1 = kid_fma(cos_rot, va, -(sin_rot * t)); if (!unrot) { ua = r0; va = r1; }
+    t = ssh_x; r0 = kid_fma(cos_rot, t, sin_rot * ssh_y); r1 = kid_fma(cos_rot, ssh_y, -(sin_rot * t)); if (!unrot) { ssh_x = r0; ssh_y = r1; }
+  }
+  if constexpr (!NANFREE) {   // IB:4869-4870
+    if (ssh_x != ssh_x) ssh_x = 0.;
+    if (ssh_y != ssh_y) ssh_y = 0.;
+  }
   e.uo = uo; e.vo = vo; e.ui = ui; e.vi = vi; e.ua = ua; e.va = va; e.ssh_x = ssh_x; e.ssh_y = ssh_y;
   e.sst = cell.t0(0); e.sss = cell.t0(1); e.cn = cell.t0(2); e.hi = cell.t0(3); e.od = cell.t0(4);
 }
@@ -585,21 +649,31 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   double wmod = kid_fma(uwave, uwave, vwave * vwave);
   const double ampl = 0.5 * 0.02025 * wmod, Lwavelength = 0.32 * wmod;
   const double Lcutoff = 0.125 * Lwavelength, Ltop = 0.25 * Lwavelength;
+#ifdef KID_EXACT_MATH
   const double Cr = 0.06 * dmin(dmax(0., kid_div(ap.L - Lcutoff, (Ltop - Lcutoff) + 1.e-30)), 1.);
-#ifdef KID_EXACT_MATH
   double wave_rad = ap.pref_wave * Cr * GRAVITY * ampl * dmin(ampl, ap.F) * ap.WL2 * ap.rWpL;
-#else
-  double wave_rad = ap.wave_q * Cr * ampl * dmin(ampl, ap.F);
-#endif
-#ifdef KID_EXACT_MATH
   wmod = kid_sqrt(kid_fma(ua, ua, va * va));
   if (wmod != 0.) { const Rcp rw = kid_rcp(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
 #else
-  wmod = kid_fma(ua, ua, va * va);   // the unit vector of the wind: one Newton-refined reciprocal square root instead of a root and a reciprocal
-  if (wmod != 0.) { const double rw = kid_rsqrt(wmod); uwave = ua * rw; vwave = va * rw; } else { uwave = 0.; vwave = 0.; wave_rad = 0.; }
+  // min(max(0, q), 1) of q = (L - Lcutoff) / (Ltop - Lcutoff + 1e-30) is 1 exactly when the numerator is not below the
+  // denominator -- any berg longer than a quarter of the wave length, i.e. nearly all of them: the division is done only in waves
+  // that hold a shorter one (each lane's value is the same either way)
+  const double cr_num = ap.L - Lcutoff, cr_den = (Ltop - Lcutoff) + 1.e-30;
+  double cr_q = 1.;
+  if (__ballot(!(cr_num >= cr_den)) != 0ull) cr_q = dmin(dmax(0., kid_div(cr_num, cr_den)), 1.);
+  const double Cr = 0.06 * cr_q;
+  const double wave_rad = ap.wave_q * Cr * ampl * dmin(ampl, ap.F);
+  // the unit vector of the wind from one Newton-refined reciprocal square root.  No wind: ua = va = 0, and 0 times the (finite)
+  // root of the floor is the reference's uwave = vwave = 0; its wave_rad = 0 only ever multiplies them
+  wmod = kid_fma(ua, ua, va * va);
+  { const double rw = kid_rsqrt(__builtin_fmax(wmod, 1.e-300)); uwave = ua * rw; vwave = va * rw; }
 #endif
   double c_ice = ap.c_ice;
-  if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.;
+  // no lane of the wave has sea ice (c_ice = 0 everywhere, e.g. config 2): drag_ice = 0 * (...) is 0 whatever the
+  // speeds are, so its square roots and its terms of the sums below are skipped -- the same numbers
+  const bool any_ice = __ballot(c_ice != 0.) != 0ull;
+  if (any_ice) { if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.; }
+  const bool has_gnd = Sw<K>::cdrag_grounding(p) != 0.;   // (c_gnd = 0 otherwise, accel_pre)
   const double ex = -GRAVITY * e.ssh_x + wave_rad * uwave, ey = -GRAVITY * e.ssh_y + wave_rad * vwave;  // IB:2142-2149
   double axn_l, ayn_l, bxn_l, byn_l;
   if (RK) { axn_l = 0.; ayn_l = 0.; bxn_l = ex + f_cori * vvel; byn_l = ey - f_cori * uvel; }          // IB:2172-2173
@@ -607,13 +681,10 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   double uveln = new_pc ? uvel0 : uvel, vveln = new_pc ? vvel0 : vvel;
   // the |V0 - V_x| halves of the predictive-corrective drag do not change between the two passes
   double s0o = 0., s0a = 0., s0i = 0.;
-  // no lane of the wave has sea ice (c_ice = 0 everywhere, e.g. config 2): drag_ice = 0 * (...) is 0 whatever the
-  // speeds are, so its three square roots per pass are skipped -- bitwise the same result
-  const bool any_ice = __ballot(c_ice != 0.) != 0ull;
   if (new_pc) {
-    s0o = kid_sqrt(kid_fma((uvel0 - uo), (uvel0 - uo), (vvel0 - vo) * (vvel0 - vo)));
-    s0a = kid_sqrt(kid_fma((uvel0 - ua), (uvel0 - ua), (vvel0 - va) * (vvel0 - va)));
-    if (any_ice) s0i = kid_sqrt(kid_fma((uvel0 - ui), (uvel0 - ui), (vvel0 - vi) * (vvel0 - vi)));
+    s0o = kid_sqrt_nn(kid_fma((uvel0 - uo), (uvel0 - uo), (vvel0 - vo) * (vvel0 - vo)));
+    s0a = kid_sqrt_nn(kid_fma((uvel0 - ua), (uvel0 - ua), (vvel0 - va) * (vvel0 - va)));
+    if (any_ice) s0i = kid_sqrt_nn(kid_fma((uvel0 - ui), (uvel0 - ui), (vvel0 - vi) * (vvel0 - vi)));
   }
   const double A12_0 = RK ? -0. * dt * f_cori : (-1. * dt * f_cori) / 2.;  // IB:2244-2251 (alpha, C_N)
   const double A21_0 = RK ? 0. * dt * f_cori : (1. * dt * f_cori) / 2.;
@@ -622,20 +693,36 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   for (int itloop = 1; itloop <= 2; ++itloop) {  // IB:2183-2277
     double drag_ocn, drag_atm, drag_ice;
     if (new_pc) {
-      drag_ocn = c_ocn * 0.5 * (kid_sqrt(kid_fma((uveln - uo), (uveln - uo), (vveln - vo) * (vveln - vo))) + s0o);
-      drag_atm = c_atm * 0.5 * (kid_sqrt(kid_fma((uveln - ua), (uveln - ua), (vveln - va) * (vveln - va))) + s0a);
-      drag_ice = any_ice ? c_ice * 0.5 * (kid_sqrt(kid_fma((uveln - ui), (uveln - ui), (vveln - vi) * (vveln - vi))) + s0i) : 0.;
+      drag_ocn = c_ocn * 0.5 * (kid_sqrt_nn(kid_fma((uveln - uo), (uveln - uo), (vveln - vo) * (vveln - vo))) + s0o);
+      drag_atm = c_atm * 0.5 * (kid_sqrt_nn(kid_fma((uveln - ua), (uveln - ua), (vveln - va) * (vveln - va))) + s0a);
+      drag_ice = any_ice ? c_ice * 0.5 * (kid_sqrt_nn(kid_fma((uveln - ui), (uveln - ui), (vveln - vi) * (vveln - vi))) + s0i) : 0.;
     } else {
+#ifdef KID_EXACT_MATH
       const double us = 0.5 * (uveln + uvel), vs = 0.5 * (vveln + vvel);
-      drag_ocn = c_ocn * kid_sqrt(kid_fma((us - uo), (us - uo), (vs - vo) * (vs - vo)));
-      drag_atm = c_atm * kid_sqrt(kid_fma((us - ua), (us - ua), (vs - va) * (vs - va)));
-      drag_ice = any_ice ? c_ice * kid_sqrt(kid_fma((us - ui), (us - ui), (vs - vi) * (vs - vi))) : 0.;
+#else
+      // first pass: uveln is uvel itself, and 0.5 (u + u) = u exactly
+      const double us = (itloop == 1) ? uvel : 0.5 * (uveln + uvel), vs = (itloop == 1) ? vvel : 0.5 * (vveln + vvel);
+#endif
+      drag_ocn = c_ocn * kid_sqrt_nn(kid_fma((us - uo), (us - uo), (vs - vo) * (vs - vo)));
+      drag_atm = c_atm * kid_sqrt_nn(kid_fma((us - ua), (us - ua), (vs - va) * (vs - va)));
+      drag_ice = any_ice ? c_ice * kid_sqrt_nn(kid_fma((us - ui), (us - ui), (vs - vi) * (vs - vi))) : 0.;
     }
     const double drag_gnd = c_gnd;
+#ifdef KID_EXACT_MATH
     double RHS_x = (axn_l / 2) + bxn_l, RHS_y = (ayn_l / 2) + byn_l;
     RHS_x = RHS_x - drag_ocn * (u_star - uo) - drag_atm * (u_star - ua) - drag_ice * (u_star - ui) - drag_gnd * u_star;  // beta=1
     RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va) - drag_ice * (v_star - vi) - drag_gnd * v_star;
     const double lambda = drag_ocn + drag_atm + drag_ice + drag_gnd;
+#else
+    // the same sums in the same order, without the terms that are 0 times something (RK: axn = 0; no ice in the wave; no
+    // grounding drag in the namelist): x - 0 * y = x
+    double RHS_x = RK ? bxn_l : (axn_l / 2) + bxn_l, RHS_y = RK ? byn_l : (ayn_l / 2) + byn_l;
+    RHS_x = RHS_x - drag_ocn * (u_star - uo) - drag_atm * (u_star - ua);  // beta=1
+    RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va);
+    double lambda = drag_ocn + drag_atm;
+    if (any_ice) { RHS_x = RHS_x - drag_ice * (u_star - ui); RHS_y = RHS_y - drag_ice * (v_star - vi); lambda = lambda + drag_ice; }
+    if (has_gnd) { RHS_x = RHS_x - drag_gnd * u_star; RHS_y = RHS_y - drag_gnd * v_star; lambda = lambda + drag_gnd; }
+#endif
     const double A11 = kid_fma(dt, lambda, 1.), A22 = A11;
 #ifdef KID_EXACT_MATH
     constexpr bool diagonal = false;
@@ -711,10 +798,10 @@ __device__ __forceinline__ void adjust_index_slow(const DevGrid &g, const kid_pa
   bilin_lonlat(g, p, i, j, xi, yj, lon, lat);
   (void)pos_within_cell<false>(g, p, GlbCell{g, g.idx(i, j)}, lon, lat, i, j, xi, yj, err, unused_bail);
 }
-template <bool FAST, int K = 0>
+template <bool FAST, int K = 0, bool HAVE_RI = false>
 __device__ __forceinline__ void adjust_index_and_ground(const DevGrid &g, const kid_params &p, const lds_double *pk, double &lon, double &lat,
-                                                        int &i, int &j, double &xi, double &yj, int &err, bool &bail) {
-  if (pos_within_cell<FAST, K>(g, p, CellOf<FAST>::make(g, pk, i, j), lon, lat, i, j, xi, yj, err, bail)) return;  // the common case: still in its cell
+                                                        int &i, int &j, double &xi, double &yj, int &err, bool &bail, const RectInv ri = RectInv{}) {
+  if (pos_within_cell<FAST, K, HAVE_RI>(g, p, CellOf<FAST>::make(g, pk, i, j), lon, lat, i, j, xi, yj, err, bail, ri)) return;  // the common case: still in its cell
   if (FAST) bail = true;
   else adjust_index_slow(g, p, lon, lat, i, j, xi, yj, err);
 }
@@ -828,10 +915,17 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   // build) or carries its environment with it (.not.old_interp_flds_order), per stage otherwise
   constexpr bool PRE_ONCE = FAST || !OLD_ORDER;
   AccelPre ap;
+  RectInv ri = {};
+#ifdef KID_EXACT_MATH
+  constexpr bool HAVE_RI = false;
+#else
+  constexpr bool HAVE_RI = FAST;
+#endif
   if constexpr (FAST) {
     const PkCell cell{pk};
     if (!cell.hotok()) { bail = true; return; }
     if (OLD_ORDER) ap = accel_pre<K>(g, p, bg, cell.t0(3), cell.t0(4));
+    if constexpr (HAVE_RI) ri = rect_inv(cell.corners());   // (used by the lanes whose cell is rect())
   }
   if (!OLD_ORDER) ap = accel_pre<K>(g, p, bg, stored.hi, stored.od);
   // hot build: no lane of the wave in a cell with sea ice -> the ice velocity is not interpolated (interp_flds)
@@ -847,7 +941,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     KID_MARK("loop_top"); KID_TICK(s == 0 ? 0 : 5);
-    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST, K>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail); }  // IB:7430-7431
+    if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST, K, HAVE_RI>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail, ri); }  // IB:7430-7431
     KID_PHASE_FENCE();
     KID_MARK("after_adjust"); KID_TICK(1);
     LatTerms lt;
@@ -857,7 +951,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
     KID_PHASE_FENCE();
     double axn_s = d.axn, ayn_s = d.ayn, ax, ay;               // IB:7400-7401
     KID_MARK("after_latterms"); KID_TICK(2);
-    if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e, need_ice);
+    if (OLD_ORDER) interp_flds<K, FAST>(p, CellOf<FAST>::make(g, pk, i, j), xi, yj, e, need_ice);
     if constexpr (!PRE_ONCE) ap = accel_pre<K>(g, p, bg, e.hi, e.od);
     KID_PHASE_FENCE();
     KID_MARK("after_interp"); KID_TICK(3);
@@ -916,7 +1010,7 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   }
   i = i1; j = j1; xi = xi1; yj = yj1;
   KID_PHASE_FENCE();
-  adjust_index_and_ground<FAST, K>(g, p, pk, lonn, latn, i, j, xi, yj, err, bail);
+  adjust_index_and_ground<FAST, K, HAVE_RI>(g, p, pk, lonn, latn, i, j, xi, yj, err, bail, ri);
   if (Sw<K>::override_iceberg_velocities(p)) { uveln = p.u_override; vveln = p.v_override; }  // IB:7151-7154
   d.lon = lonn; d.lat = latn; d.uvel = uveln; d.vvel = vveln; d.axn = axn; d.ayn = ayn; d.bxn = bxn; d.byn = byn;
   d.xi = xi; d.yj = yj; d.ine = i; d.jne = j;
@@ -939,7 +1033,7 @@ __device__ __forceinline__ void verlet_step(const DevGrid &g, const kid_params &
   if constexpr (FAST) { if (!PkCell{pk}.hotok() || ((lat1 > 89.) && g.latlon)) { bail = true; return; } }
   const LatTerms lt = lat_terms<K>(g, p, lat1, sin_ref);
   Env e = stored;
-  if (OLD_ORDER) interp_flds<K>(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e);
+  if (OLD_ORDER) interp_flds<K, FAST>(p, CellOf<FAST>::make(g, pk, d.ine, d.jne), d.xi, d.yj, e);
   const AccelPre ap = accel_pre<K>(g, p, bg, e.hi, e.od);
   KID_PHASE_FENCE();
   KID_TICK(3);

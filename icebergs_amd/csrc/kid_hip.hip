@@ -101,9 +101,19 @@ __global__ void __launch_bounds__(256) pack_packets_kernel(const DevGrid g, doub
       const int i = ib + u;
       if (i >= i1) continue;
       const bool interior = row_inside && i >= 1 && i < g.ni - 1;
+      // the packet's flag word (PkCell::flags): +-(1 + 2 [sides along the axes] + 4 [unrotated: cos = 1, sin = 0 at the four
+      // corners]), positive where the hot build may step a berg of the cell (DevGrid::hotok, and no NaN among the
+      // sea-surface-slope stencil values: IB:4869-4870 stays with the general build); 0 on the rim of the data domain
+      const bool is_cos = lane < PK_CORNER && (lane & 7) == 0, is_sin = lane < PK_CORNER && (lane & 7) == 1;
+      const bool rotated = __ballot((is_cos && a[u] != 1.) || (is_sin && a[u] != 0.)) != 0ull;
+      const bool nan_stencil = __ballot(lane >= PK_DDX && lane < PK_AREA && a[u] != a[u]) != 0ull;
       double *o = pkt + ((long long)j * g.ni + i) * PK_GSTRIDE;
       o[lane] = interior ? a[u] : 0.;
-      if (second) o[64 + lane] = interior ? a2[u] : ((64 + lane == PK_HOTOK) ? g.hotok[(long long)j * g.ni + i] : 0.);
+      if (second) {
+        double v = interior ? a2[u] : 0.;
+        if (64 + lane == PK_HOTOK) v = interior ? ((v != 0. && !nan_stencil) ? 1. : -1.) * (1. + (v == 2. ? 2. : 0.) + (rotated ? 0. : 4.)) : 0.;
+        o[64 + lane] = v;
+      }
     }
   }
 }

@@ -23,15 +23,19 @@ struct Flags { int has_static, has_fl, store_env, footprint, no_diag; };   // no
 // LDS read would also wait for the loads still in flight.  These go through the global address space explicitly.
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) int32_t gint32;
-__device__ __forceinline__ double ldg(const double *q, long long k) { return ((const gdouble *)q)[k]; }
-__device__ __forceinline__ int32_t ldg(const int32_t *q, long long k) { return ((const gint32 *)q)[k]; }
+typedef __attribute__((address_space(1))) char gchar;
+// Row k of a field: the field's base is wave-uniform (a scalar register pair read from the table) and the byte offset of the row
+// fits 32 bits (kid_create refuses more than 2^29 rows), so one 32-bit offset register serves every field of the row
+// (global_load ... v_off, s[base:base+1]) instead of a 64-bit address computed per field and row.
+__device__ __forceinline__ double ldg(const double *q, long long k) { return *(const gdouble *)((const gchar *)q + (size_t)((unsigned)k << 3)); }
+__device__ __forceinline__ int32_t ldg(const int32_t *q, long long k) { return *(const gint32 *)((const gchar *)q + (size_t)((unsigned)k << 2)); }
 // keep(x): an empty use of x.  The per-berg loads at the head of the kernel are written before the early exit of an
 // all-dead wave so that they are all in flight at once; values used on the live path only would be sunk below that branch
 // by the compiler, behind the wait for `alive` -- a second round trip to HBM per wave.  The dead path "uses" them too.
 __device__ __forceinline__ void keep(double x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void keep(int32_t x) { asm volatile("" ::"v"(x)); }
-__device__ __forceinline__ void stg(double *q, long long k, double v) { ((gdouble *)q)[k] = v; }
-__device__ __forceinline__ void stg(int32_t *q, long long k, int32_t v) { ((gint32 *)q)[k] = v; }
+__device__ __forceinline__ void stg(double *q, long long k, double v) { *(gdouble *)((gchar *)q + (size_t)((unsigned)k << 3)) = v; }
+__device__ __forceinline__ void stg(int32_t *q, long long k, int32_t v) { *(gint32 *)((gchar *)q + (size_t)((unsigned)k << 2)) = v; }
 // the plain build (K = 1, kid_device.hpp) is launched only with all five flags zero
 template <int K> struct Fl {
 #define KID_X(name) static __device__ __forceinline__ int name(const Flags &f) { if constexpr (K == 1) return 0; else return f.name; }
@@ -82,7 +86,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
   constexpr int WG_WAVES = FAST ? KID_HOT_WG / 64 : 4;   // (the general build is launched one wave per workgroup; its other entry points with up to four)
   __shared__ double lds_vals[SCATTER ? seg_lds_doubles(WG_WAVES) : 1];   // staging of the per-cell sums (kid_thermo.hpp)
   __shared__ int lds_ints[seg_lds_ints(WG_WAVES)];                         // run tables of the workgroup's waves
-  __shared__ double lds_pk[FAST ? WG_WAVES * KID_MAXRUN * PK_STRIDE : 1];   // cell packets of the workgroup's waves (hot build)
+  __shared__ __attribute__((aligned(16))) double lds_pk[FAST ? WG_WAVES * KID_MAXRUN * PK_STRIDE : 2];   // cell packets of the workgroup's waves (hot build)
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
   const long long total = FAST ? redo.klen : (long long)(*redo.count);
   const long long bdim = FAST ? (long long)KID_HOT_WG : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
@@ -164,25 +168,22 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
     // population (5 bergs per cell), 58 % of that wave's lifetime (tools/profiling/time_segments_c3.py), and the reason the
     // kernel slowed down as the cell order decayed between re-binnings.  (A run without a cell loads cell 0's packet and
     // does not store it.)
-    const gdouble *gp = (const gdouble *)g.pkt + lane;
-    for (int r0 = 0; r0 < nstage; r0 += 8) {  // wave-uniform
-      int cc[8]; double a[8], a2[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) cc[u] = (r0 + u < nstage) ? seg.cell[r0 + u] : -1;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long long off = (long long)(cc[u] >= 0 ? cc[u] : 0) * PK_GSTRIDE;
-        a[u] = gp[off];
-        a2[u] = gp[off + ((lane < PK_SIZE - 64) ? 64 : 0)];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (cc[u] >= 0) {
-          wpk[(r0 + u) * PK_STRIDE + lane] = a[u];
-          if (lane < PK_SIZE - 64) wpk[(r0 + u) * PK_STRIDE + 64 + lane] = a2[u];
-        }
-      }
+    // The packets go from memory straight into LDS (gfx950: global_load_lds_dwordx4, 16 bytes per lane, lane l to LDS base + 16 l):
+    // one instruction per cell with the first 34 lanes moves the 544-byte packet, no staging registers, and every cell's load is
+    // in flight before the single wait.  The cell of a run is wave-uniform (one LDS read, a v_readlane per run): scalar address
+    // arithmetic, and runs that do not exist cost nothing (the unrolled register staging it replaces issued the loads of eight
+    // cells whatever the wave held -- ~10 vector instructions per slot).
+    const gchar *gp = (const gchar *)g.pkt;
+    static_assert(PK_SIZE * 8 == 34 * 16 && (PK_STRIDE * 8) % 16 == 0 && (PK_GSTRIDE * 8) % 16 == 0, "packet = 34 lanes x 16 bytes, 16-byte aligned slots");
+    const int mycell = seg.cell[lane < KID_MAXRUN ? lane : 0];
+    const unsigned loff = (unsigned)lane * 16u;
+    for (int u = 0; u < nstage; ++u) {  // wave-uniform
+      const int cu = __builtin_amdgcn_readlane(mycell, u);
+      if (cu >= 0 && lane < 34)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)cu * (size_t)(PK_GSTRIDE * 8) + loff),
+                                         (__attribute__((address_space(3))) void *)(wpk + u * PK_STRIDE), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     pk = wpk + (myrun < KID_MAXRUN ? myrun : 0) * PK_STRIDE;
   }

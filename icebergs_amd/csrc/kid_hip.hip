@@ -560,6 +560,7 @@ const char *kid_last_error(const kid_handle *h) { return h ? h->err.c_str() : "n
 
 int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capacity, int device, kid_handle **out) {
   if (!grid || !params || !out || capacity <= 0) return KID_EINVAL;
+  if (capacity > (int64_t(1) << 29)) return KID_EINVAL;   // the per-berg kernel addresses a row by a 32-bit byte offset (2^29 rows of 8 bytes; 240 GB of berg state)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KID_ENODEV;
   if (device < 0 || device >= ndev) return KID_ENODEV;

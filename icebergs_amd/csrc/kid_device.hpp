@@ -470,10 +470,9 @@ __device__ __forceinline__ bool pos_within_cell(const DevGrid &g, const kid_para
       // calc_xiyj on a cell whose sides lie along the axes: beta, delta, gamma, kappa and the quadratic coefficient are exact
       // zeros, and what is left of its linear branch is this -- the same operations on the same values, bit for bit
       const double dx = mod_around(x, q.lon00, g.Lx) - q.lon00, dy = y - q.lat00;
-      if constexpr (HAVE_RI) {
-        const double c = ri.alpha * dy;
-        yj = (ri.b != 0.) ? kid_div_r(-c, ri.b, ri.rb) : 0.;
-        if (ri.alpha != 0.) xi = kid_div_r(dx, ri.alpha, ri.ra); else { err = 1; xi = -999.; }
+      if constexpr (HAVE_RI) {   // (alpha and b are not 0: a berg of a degenerate cell has bailed, rk4_step)
+        yj = kid_div_r(-(ri.alpha * dy), ri.b, ri.rb);
+        xi = kid_div_r(dx, ri.alpha, ri.ra);
       } else {
         const double alpha = q.lon10 - q.lon00, epsilon = q.lat01 - q.lat00;
         const double b = -(alpha * epsilon), c = alpha * dy;
@@ -551,24 +550,26 @@ __device__ __forceinline__ void interp_flds(const kid_params &p, const CELL &cel
     vo = vo + cd * (mN - mS) * m0;
     vi = vi + cd * (mN - mS) * m0;
   }
-  // sea-surface slope from the hoisted per-cell stencils (IB:4830-4860)
-  double hxp, hxm;
-  if (yj >= 0.5) {
-    hxp = kid_fma(yj - 0.5, cell.ddx(0), (1.5 - yj) * cell.ddx(1));
-    hxm = kid_fma(yj - 0.5, cell.ddx(3), (1.5 - yj) * cell.ddx(4));
-  } else {
-    hxp = kid_fma(yj + 0.5, cell.ddx(1), (0.5 - yj) * cell.ddx(2));
-    hxm = kid_fma(yj + 0.5, cell.ddx(4), (0.5 - yj) * cell.ddx(5));
+  // sea-surface slope from the hoisted per-cell stencils (IB:4830-4860).  The reference's two branches (yj >= 0.5 or not) are
+  // the same expression on neighbouring stencil rows with weights shifted by one: the row and the two constants are picked per
+  // lane and the expression is evaluated once (the same operations on the same values as the branch the lane would have taken)
+  double ssh_x, ssh_y;
+  {
+    const bool up = yj >= 0.5;
+    const int k = up ? 0 : 1;
+    const double wa = yj + (up ? -0.5 : 0.5), wb = (up ? 1.5 : 0.5) - yj;
+    const double hxp = kid_fma(wa, cell.ddx(k), wb * cell.ddx(k + 1));
+    const double hxm = kid_fma(wa, cell.ddx(k + 3), wb * cell.ddx(k + 4));
+    ssh_x = kid_fma(xi, hxp, (1. - xi) * hxm);
   }
-  double ssh_x = kid_fma(xi, hxp, (1. - xi) * hxm);
-  if (xi >= 0.5) {
-    hxp = kid_fma(xi - 0.5, cell.ddy(0), (1.5 - xi) * cell.ddy(1));
-    hxm = kid_fma(xi - 0.5, cell.ddy(3), (1.5 - xi) * cell.ddy(4));
-  } else {
-    hxp = kid_fma(xi + 0.5, cell.ddy(1), (0.5 - xi) * cell.ddy(2));
-    hxm = kid_fma(xi + 0.5, cell.ddy(4), (0.5 - xi) * cell.ddy(5));
+  {
+    const bool up = xi >= 0.5;
+    const int k = up ? 0 : 1;
+    const double wa = xi + (up ? -0.5 : 0.5), wb = (up ? 1.5 : 0.5) - xi;
+    const double hyp = kid_fma(wa, cell.ddy(k), wb * cell.ddy(k + 1));
+    const double hym = kid_fma(wa, cell.ddy(k + 3), wb * cell.ddy(k + 4));
+    ssh_y = kid_fma(yj, hyp, (1. - yj) * hym);
   }
-  double ssh_y = kid_fma(yj, hxp, (1. - yj) * hxm);
   // rotate to lat-lon (IB:4953-4967)
   if (!all_unrot) {
     double t, r0, r1;
@@ -720,8 +721,9 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
     RHS_x = RHS_x - drag_ocn * (u_star - uo) - drag_atm * (u_star - ua);  // beta=1
     RHS_y = RHS_y - drag_ocn * (v_star - vo) - drag_atm * (v_star - va);
     double lambda = drag_ocn + drag_atm;
-    if (any_ice) { RHS_x = RHS_x - drag_ice * (u_star - ui); RHS_y = RHS_y - drag_ice * (v_star - vi); lambda = lambda + drag_ice; }
-    if (has_gnd) { RHS_x = RHS_x - drag_gnd * u_star; RHS_y = RHS_y - drag_gnd * v_star; lambda = lambda + drag_gnd; }
+    // (the empty asm keeps each block a branch: speculated, the compiler evaluates the terms anyway and selects)
+    if (any_ice) { asm volatile(""); RHS_x = RHS_x - drag_ice * (u_star - ui); RHS_y = RHS_y - drag_ice * (v_star - vi); lambda = lambda + drag_ice; }
+    if (has_gnd) { asm volatile(""); RHS_x = RHS_x - drag_gnd * u_star; RHS_y = RHS_y - drag_gnd * v_star; lambda = lambda + drag_gnd; }
 #endif
     const double A11 = kid_fma(dt, lambda, 1.), A22 = A11;
 #ifdef KID_EXACT_MATH
@@ -925,7 +927,10 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
     const PkCell cell{pk};
     if (!cell.hotok()) { bail = true; return; }
     if (OLD_ORDER) ap = accel_pre<K>(g, p, bg, cell.t0(3), cell.t0(4));
-    if constexpr (HAVE_RI) ri = rect_inv(cell.corners());   // (used by the lanes whose cell is rect())
+    if constexpr (HAVE_RI) {
+      ri = rect_inv(cell.corners());   // (used by the lanes whose cell is rect())
+      if (cell.rect() && (ri.alpha == 0. || ri.b == 0.)) { bail = true; return; }   // a degenerate cell: the general build reports it
+    }
   }
   if (!OLD_ORDER) ap = accel_pre<K>(g, p, bg, stored.hi, stored.od);
   // hot build: no lane of the wave in a cell with sea ice -> the ice velocity is not interpolated (interp_flds)

@@ -3,14 +3,17 @@
 //   find_cell  FW:6011-6040      generate_id  FW:4165-4179
 // A calving event is rare (a parent sheds a child every few hundred steps), so this is a short streaming kernel
 // between the evolve and the thermodynamics launches.  New bergs are appended behind the population through an
-// atomic cursor; their ids come from the per-cell counter of the parent's cell (atomic, so ids are unique; when
-// two bergs of one cell calve in the same step the reference hands the counter values out in list order, here
-// the order is the atomics').  displace_fl_bergs: the child's place on the parent's perimeter comes from the counter-
+// atomic cursor.  Their ids come from the per-cell counter of the parent's cell (generate_id FW:4165-4179), which the reference
+// hands out in the order its loop meets the events: cells j outer / i inner, a cell's bergs in list order (`inorder`), a
+// berg's calving event before its new-berg-from-bits event.  Here a child first gets a provisional (negative) id naming its
+// parent's row and the event, and fl_assign_ids_* (below, launched once the pass has ended) gives the children of every cell
+// their counter values in exactly that order -- the same ids whatever the schedule of the lanes.  displace_fl_bergs: the child's place on the parent's perimeter comes from the counter-
 // based generator of include/kid_rng.h, keyed by (seed, parent id, footloose step, draw) -- the reference draws from
 // FMS's sequential stream in traversal order, which has no counterpart on a GPU; what follows the number (side and
 // offset, metres -> degrees, find_cell and its corner / grounded-cell fall-backs, pos_within_cell) is the reference's.
-// The "new berg from FL bits" branch uses l_b of the berg at hand (the reference reuses the local left by the
-// previous berg of the loop, IB:2667).
+// The "new berg from FL bits" branch hands calve_fl_icebergs the local l_b left by the last ELIGIBLE berg of the loop (IB:2573,
+// 2667) -- a stale value for a footloose child (fl_k < 0) that holds bits -- but with berg_from_bits present that dummy argument
+// is never read (IB:6488-6497 take the dimensions from fl_bits_dimensions; l_b is read at IB:6499-6501 only): nothing to reproduce.
 #pragma once
 #include "kid_device.hpp"
 #include "kid_thermo.hpp"
@@ -136,11 +139,8 @@ __device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, 
   b.f[KID_B_MASS_OF_FL_BITS][c] = 0.0; b.f[KID_B_MASS_OF_FL_BERGY_BITS][c] = 0.0;
   b.f[KID_B_FL_K][c] = -1.0;
   b.i[KID_BI_START_YEAR][c] = p.current_year;
-  {  // generate_id FW:4165-4179 at the parent's cell
-    const int32_t cnt = atomicAdd(cx.counter + g.idx(pi, pj), 1) + 1;
-    const int32_t ij = pi + (cx.iNg * (pj - 1));
-    b.id[c] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)ij;
-  }
+  // provisional id: -(1 + 2 * parent row + event); fl_assign_ids_* replaces it by generate_id's value (FW:4165-4179)
+  b.id[c] = -(((int64_t)pk << 1 | (from_bits ? 1 : 0)) + 1);
   b.f[KID_B_HALO_BERG][c] = 0.0;
   const int same[] = {KID_B_START_MASS, KID_B_UVEL, KID_B_VVEL, KID_B_AXN, KID_B_AYN, KID_B_BXN, KID_B_BYN,
                       KID_B_UVEL_PREV, KID_B_VVEL_PREV, KID_B_UVEL_OLD, KID_B_VVEL_OLD, KID_B_HEAT_DENSITY,
@@ -232,6 +232,72 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
   double flk = b.f[KID_B_FL_K][q], bits = b.f[KID_B_MASS_OF_FL_BITS][q];
   bool touched = false;
   footloose_core(g, p, b, cx, q, i, j, g.geo[g.idx(i, j)].area, b.f[KID_B_MASS_SCALING][q], b.f[KID_B_STATIC_BERG][q], M, T, W, L, flk, bits, touched, acc, ncell, scal);
+}
+
+
+// ---- ids of the children of one footloose pass, in the reference's order ---------------------------------------------------
+// rows [n_old, n_old + m) hold the children with provisional ids.  Events per pass are few (~1e-4 of the bergs), events per
+// cell one, rarely two: every child pushes itself on its parent cell's list (head[cell], next[]), then counts the children of
+// that list that the reference's loop meets before it -- parents compared by the `inorder` keys (FW:4318-4359), equal keys by
+// the parent's id, one parent's two events by the event -- and takes counter + 1 + that count.
+struct FlIdCtx { int32_t *head, *next; int64_t *newid; int32_t *counter; long long n_old; int m; int iNg; };
+__device__ __forceinline__ void fl_event_of(const int64_t prov, long long &parent, int &ev) {
+  const int64_t v = -prov - 1;
+  parent = (long long)(v >> 1); ev = (int)(v & 1);
+}
+template <class BP>
+__device__ __forceinline__ bool fl_event_before(const BP &b, long long pa, int ea, long long pb, int eb) {   // a strictly before b
+  if (pa == pb) return ea < eb;
+  const int ya = b.i[KID_BI_START_YEAR][pa], yb = b.i[KID_BI_START_YEAR][pb];
+  if (ya != yb) return ya < yb;
+  const int keys[4] = {KID_B_START_DAY, KID_B_START_MASS, KID_B_START_LON, KID_B_START_LAT};
+  for (int q = 0; q < 4; ++q) {
+    const double va = b.f[keys[q]][pa], vb = b.f[keys[q]][pb];
+    if (va < vb) return true;
+    if (va > vb) return false;
+  }
+  return b.id[pa] < b.id[pb];
+}
+template <class BP>
+__global__ void __launch_bounds__(256) fl_assign_ids_push(const DevGrid g, const BP *bt, const FlIdCtx x) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= x.m) return;
+  const BP &b = *bt;
+  long long pr; int ev;
+  fl_event_of(b.id[x.n_old + e], pr, ev);
+  const int cell = g.idx(b.i[KID_BI_INE][pr], b.i[KID_BI_JNE][pr]);
+  x.next[e] = atomicExch(x.head + cell, e);
+}
+template <class BP>
+__global__ void __launch_bounds__(256) fl_assign_ids_rank(const DevGrid g, const BP *bt, const FlIdCtx x) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= x.m) return;
+  const BP &b = *bt;
+  long long pr; int ev;
+  fl_event_of(b.id[x.n_old + e], pr, ev);
+  const int pi = b.i[KID_BI_INE][pr], pj = b.i[KID_BI_JNE][pr];
+  const int cell = g.idx(pi, pj);
+  int before = 0;
+  for (int o = x.head[cell]; o >= 0; o = x.next[o]) {
+    if (o == e) continue;
+    long long po; int eo;
+    fl_event_of(b.id[x.n_old + o], po, eo);
+    if (fl_event_before(b, po, eo, pr, ev)) ++before;
+  }
+  const int32_t cnt = x.counter[cell] + 1 + before;          // generate_id: the counter is incremented, then used
+  x.newid[e] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)(pi + (x.iNg * (pj - 1)));
+}
+template <class BP>
+__global__ void __launch_bounds__(256) fl_assign_ids_store(const DevGrid g, const BP *bt, const FlIdCtx x) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= x.m) return;
+  const BP &b = *bt;
+  long long pr; int ev;
+  fl_event_of(b.id[x.n_old + e], pr, ev);   // (every lane decodes its own provisional id only)
+  const int cell = g.idx(b.i[KID_BI_INE][pr], b.i[KID_BI_JNE][pr]);
+  atomicAdd(x.counter + cell, 1);           // (integer: the order of the adds does not matter)
+  x.head[cell] = -1;                        // (the same value from every child of the cell: the lists are empty again)
+  b.id[x.n_old + e] = x.newid[e];
 }
 
 }  // namespace kid

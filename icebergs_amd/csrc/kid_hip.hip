@@ -411,6 +411,7 @@ struct kid_handle {
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   unsigned fl_step = 0;                  // footloose passes so far: third counter word of the child-placement generator (kid_rng.h)
   int *d_fl_cursor = nullptr;
+  int32_t *d_fl_head = nullptr, *d_fl_next = nullptr; int64_t *d_fl_newid = nullptr; long long fl_ev_capacity = 0;   // fl_assign_ids_*
   unsigned *d_key[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};  // radix-sort ping-pong buffers
   void *d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   double *d_perm_spare = nullptr;
@@ -695,6 +696,9 @@ int kid_destroy(kid_handle *h) {
   if (h->d_cscan_tmp) (void)hipFree(h->d_cscan_tmp);
   if (h->d_iceberg_counter) (void)hipFree(h->d_iceberg_counter);
   if (h->d_fl_cursor) (void)hipFree(h->d_fl_cursor);
+  if (h->d_fl_head) (void)hipFree(h->d_fl_head);
+  if (h->d_fl_next) (void)hipFree(h->d_fl_next);
+  if (h->d_fl_newid) (void)hipFree(h->d_fl_newid);
   mts_free(h);
   if (h->d_orient) (void)hipFree(h->d_orient);
   if (h->d_redo_list) (void)hipFree(h->d_redo_list);
@@ -1399,6 +1403,30 @@ static int refresh_tables(kid_handle *h) {
   }
   return KID_OK;
 }
+// ids of the children a footloose pass appended to rows [n_old, n_old + m): the per-cell counter values in the order the
+// reference's loop would have met the events (kid_footloose.hpp, fl_assign_ids_*)
+static int fl_assign_ids(kid_handle *h, long long n_old, int m) {
+  if (m <= 0) return KID_OK;
+  if (!h->d_fl_head) {
+    KID_HIP(h, hipMalloc(&h->d_fl_head, h->ncell * sizeof(int32_t)));
+    KID_HIP(h, hipMemsetAsync(h->d_fl_head, 0xff, h->ncell * sizeof(int32_t), h->stream));   // -1: empty lists
+  }
+  if (m > h->fl_ev_capacity) {
+    if (h->d_fl_next) (void)hipFree(h->d_fl_next);
+    if (h->d_fl_newid) (void)hipFree(h->d_fl_newid);
+    h->fl_ev_capacity = std::max<long long>(2ll * m, 4096);
+    KID_HIP(h, hipMalloc(&h->d_fl_next, (size_t)h->fl_ev_capacity * sizeof(int32_t)));
+    KID_HIP(h, hipMalloc(&h->d_fl_newid, (size_t)h->fl_ev_capacity * sizeof(int64_t)));
+  }
+  const FlIdCtx x{h->d_fl_head, h->d_fl_next, h->d_fl_newid, h->d_iceberg_counter, n_old, m, h->gd.iec - h->gd.isc + 1};
+  const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+  const DevGrid g = dev_grid(h);
+  hipLaunchKernelGGL(fl_assign_ids_push<BergPtrs>, grid, block, 0, h->stream, g, (const BergPtrs *)h->d_bp, x);
+  hipLaunchKernelGGL(fl_assign_ids_rank<BergPtrs>, grid, block, 0, h->stream, g, (const BergPtrs *)h->d_bp, x);
+  hipLaunchKernelGGL(fl_assign_ids_store<BergPtrs>, grid, block, 0, h->stream, g, (const BergPtrs *)h->d_bp, x);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
 int kid_footloose_calving(kid_handle *h) {
   if (!h) return KID_EINVAL;
   if (!h->params.footloose || h->n == 0) return KID_OK;
@@ -1419,8 +1447,9 @@ int kid_footloose_calving(kid_handle *h) {
     h->err = "footloose calving ran out of capacity: create the handle with room for child bergs";
     return KID_ECAPACITY;
   }
+  rc = fl_assign_ids(h, h->n, appended);
   h->n += appended;
-  return KID_OK;
+  return rc;
 }
 double kid_footloose_uniform(int32_t seed, int64_t berg_id, int64_t step, int32_t draw) {   // the number a child placement uses (host side of kid_rng.h)
   return kid_fl_uniform((uint32_t)seed, berg_id, (uint32_t)step, (uint32_t)draw);
@@ -1518,6 +1547,8 @@ int kid_step_local(kid_handle *h) {
       return KID_ECAPACITY;
     }
     h->n = n_old + appended;
+    rc = fl_assign_ids(h, n_old, appended);
+    if (rc) return rc;
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h, n_old, appended) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h, n_old, appended);
   }
   if (p.footloose) {  // phase by phase (KID_FL_UNFUSED, static bergs): three launches

@@ -18,6 +18,7 @@
  */
 #include "kid_oracle.h"
 #include <stddef.h>
+#include <stdlib.h>
 #include <math.h>
 
 #define RHO_SEAWATER 1025.0
@@ -174,7 +175,12 @@ void ko_footloose_calving(const ko_grid *g, const kid_params *p, kid_berg_soa *b
   const double poisson = 0.3, youngs = p->fl_youngs;
   const double l_c = p->pi / (2. * sqrt(2.)), lw_c = 1. / (GRAVITY * RHO_SEAWATER), B_c = youngs / (12. * (1. - pow(poisson, 2.)));
   const int64_t n0 = b->n;
-  for (int64_t q = 0; q < n0; ++q) {
+  /* the loop of IB:2552-2677 in its own order: cells j outer / i inner, a cell's list in `inorder` -- the order in
+   * which generate_id hands out a cell's counter values when several of its bergs calve in one step */
+  int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n0 > 0 ? n0 : 1));
+  ko_reference_order(b, perm);
+  for (int64_t kk = 0; kk < n0; ++kk) {
+    const int64_t q = perm[kk];
     if (b->i32[KID_BI_ALIVE] && !b->i32[KID_BI_ALIVE][q]) continue;
     const int i = b->i32[KID_BI_INE][q], j = b->i32[KID_BI_JNE][q];
     if (i < g->d.isc || i > g->d.iec || j < g->d.jsc || j > g->d.jec) continue; /* computational domain only IB:2554 */
@@ -236,5 +242,6 @@ void ko_footloose_calving(const ko_grid *g, const kid_params *p, kid_berg_soa *b
       if (area != 0.) acc[(size_t)KID_A_FL_BITS_SRC * ncell + c] -= k * p->new_berg_from_fl_bits_mass_thres / (p->dt * area);
     }
   }
+  free(perm);
   g_fl_step += 1u;
 }

@@ -52,13 +52,10 @@ def test_reference_known_answers(oracle):
 
 def _check(name, res, tol_state, tol_grid, exact_ints=True, stiff=False):
     gold = np.load(os.path.join(HERE, "golden", name + ".npz"))
-    # survivors only (the library drops dead rows when it re-bins).  Footloose children of one cell born in one step may
-    # swap counter values between the two sides: group them by the cell part of the id and order by where they are.
+    # survivors only (the library drops dead rows when it re-bins), matched by id: ids are exact, a footloose child's included
     def order(d):
         idx = np.nonzero(d["b_alive"] != 0)[0]
-        ident = d["b_id"][idx]
-        primary = np.where(ident >= (1 << 32), (ident & 0xFFFFFFFF) + (1 << 40), ident)
-        return idx[np.lexsort((d["b_mass_scaling"][idx], d["b_lat"][idx], d["b_lon"][idx], primary))]
+        return idx[np.argsort(d["b_id"][idx], kind="stable")]
     og, orr = order(gold), order(res)
     assert len(og) == len(orr), "survivors"
     assert np.array_equal(np.sort(gold["b_id"][og]), np.sort(res["b_id"][orr]))

@@ -675,6 +675,7 @@ __device__ __forceinline__ void accel(const DevGrid &g, const kid_params &p, con
   const bool any_ice = __ballot(c_ice != 0.) != 0ull;
   if (any_ice) { if (fabs(ui) + fabs(vi) == 0.) c_ice = 0.; }
   const bool has_gnd = Sw<K>::cdrag_grounding(p) != 0.;   // (c_gnd = 0 otherwise, accel_pre)
+  (void)has_gnd;
   const double ex = -GRAVITY * e.ssh_x + wave_rad * uwave, ey = -GRAVITY * e.ssh_y + wave_rad * vwave;  // IB:2142-2149
   double axn_l, ayn_l, bxn_l, byn_l;
   if (RK) { axn_l = 0.; ayn_l = 0.; bxn_l = ex + f_cori * vvel; byn_l = ey - f_cori * uvel; }          // IB:2172-2173

@@ -35,7 +35,7 @@ class KidError(RuntimeError):
 
 def build(verbose=False):
     """Compile libkid_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    subprocess.run(["make", "-C", _CSRC] + ([] if verbose else ["-s"]), check=True)
+    subprocess.run(["make", "-C", _CSRC, "-j2", "all"] + ([] if verbose else ["-s"]), check=True)   # the library and its exact-math twin (tests only)
     return SO_PATH
 
 

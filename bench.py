@@ -30,7 +30,7 @@ ALGO_BYTES_PER_BERG_STEP = 256.0  # SURVEY.md 8d (config 2): 129 B read + 128 B 
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6           # MI355X vector fp64 peak
 N_SIMD, SIMD_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; one wave-instruction (64 lanes, fp64 included) issues per 4 cycles per SIMD
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")   # rocprofv3 --pmc passes of this same command (tools/profiling/run_pmc.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")   # rocprofv3 --pmc passes of this same command (tools/profiling/run_pmc.sh)
 
 
 def _cpu_worker(nbergs, nsteps, seed):
@@ -69,22 +69,100 @@ def _run_cpu_shards(nshards, nbergs, nsteps):
     return sum(o["berg_steps"] for o in outs), wall
 
 
+def _host_core_share():
+    """(cores this process may use, how that was found).  A GPU box hands a job one GPU's share of the host: the cgroup CPU quota
+    when there is one, else the visible cores divided by the node's 8 GPUs."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # v1
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, int(round(q / per)))
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        return min(visible, quota), visible, "cgroup CPU quota"
+    return max(1, visible // 8), visible, "visible cores / 8 GPUs of the node (no cgroup quota)"
+
+
 def cpu_baseline(nbergs, nsteps):
     """The CPU oracle on the host cores of this node, on a bounded cut of the same workload: one core, then P independent
-    shards on P cores.  Runs in child processes that never touch the GPU, before this process initialises it."""
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    P = max(1, min(avail, int(os.environ.get("KID_CPU_BASELINE_CORES", "16"))))   # a 1-GPU box's CPU share is 16 cores
+    shards on P cores, P = this job's share of the host (_host_core_share; KID_CPU_BASELINE_CORES overrides).
+    Runs in child processes that never touch the GPU, before this process initialises it."""
+    share, visible, rule = _host_core_share()
+    P = max(1, min(visible, int(os.environ.get("KID_CPU_BASELINE_CORES", str(share)))))
     w1, t1 = _run_cpu_shards(1, nbergs, nsteps)
     per = max(nbergs // 2, 1)
     wP, tP = _run_cpu_shards(P, per, nsteps)
     return {"value": wP / tP, "unit": "berg-steps/s", "cores": P, "kind": "port",
-            "one_core_value": w1 / t1,
+            "one_core_value": w1 / t1, "cores_visible": visible, "cores_rule": rule,
             "sample": "config 2 (same generator): 1 core: %d bergs x %d steps (%.1f s); %d cores: %d independent shards of %d bergs x %d steps, "
-                      "started together (%.1f s wall); oracle/kid_oracle.c -O2, one thread per shard; %d cores visible to this process"
-                      % (nbergs, nsteps, t1, P, P, per, nsteps, tP, avail)}
+                      "started together (%.1f s wall); oracle/kid_oracle.c -O2, one thread per shard; %d cores visible to this process, "
+                      "%d used: %s" % (nbergs, nsteps, t1, P, P, per, nsteps, tP, visible, P, rule)}
+
+
+def other_configs(np, torch, S, T, Icebergs, budget_s=75.0):
+    """BASELINE configs 3 and 4 at their full size, timed here so that the driver's record holds them too (informational: the
+    headline `value` is configs[4]'s per-GPU share above).  Each on a fresh handle, a few steps, inputs resident."""
+    out, t_start = {}, time.perf_counter()
+    # ---- config 3: 1e7 bergs, footloose profile (tests/footloose_tests/input.nml scaled to a 2000 x 1000 km periodic channel) ----
+    try:
+        n = 10_000_000
+        grid, p, b = S.config_c3(n=n, seed=3, ni=2000, nj=1000, fl_style="fl_bits", capacity_factor=1.3, dt=10.0, spread=True, displace=True, periodic=True)
+        ib = Icebergs(grid, p, capacity=len(b["lon"]), device=torch.cuda.current_device())
+        ib.upload_bergs(b)
+        ib.set_store_environment(False)   # ignore_traj=T: nobody reads berg%uo..hi back (the fused step interpolates for itself)
+        ib.run(3); ib.sync()
+        ib.profile(True)
+        steps = 12
+        t0 = time.perf_counter(); ib.run(steps); ib.sync(); dt = time.perf_counter() - t0
+        ms, launches, _ = ib.profile_get(); ib.profile(False)
+        n_slots, n_alive = ib.num_bergs()
+        kern = ms / steps      # per step: the fused launch + the short launch over the step's new children
+        out["c3"] = {"workload": "BASELINE configs[2]: 1e7 bergs, footloose (fl_bits, displaced children), Verlet, 2000x1000 periodic 1 km grid, dt=10 s",
+                     "ms_per_step": 1e3 * dt / steps, "berg_steps_per_s": n * steps / dt, "steps": steps, "bergs_alive_at_end": int(n_alive),
+                     "store_environment": False,
+                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_berg_step": 320, "kernel_ms_per_step": kern, "kernel_launches": int(launches),
+                                  "achieved": 320.0 * n / (kern * 1e-3) / 1e9 if kern > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": (320.0 * n / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern > 0 else 0.0}}
+        ib.close()
+        del ib, grid, p, b
+    except Exception as e:   # informational: never takes the headline down with it
+        out["c3"] = {"error": repr(e)}
+    # ---- config 4: 224 x 224 bonded DEM elements, 90 sub-steps per step ----
+    try:
+        if time.perf_counter() - t_start < budget_s:
+            grid, p, b, bd = S.config_c4(nx=224, ny=224, hexagonal=False, radius=1500.0, ni=60, nj=60, gridres=20000.0, sub_steps=90,
+                                         origin=(100137.0, 100211.0), bump=(900.0e3, 440.0e3))
+            ib = Icebergs(grid, p, capacity=len(b["lon"]), device=torch.cuda.current_device())
+            ib.upload_bergs(b); ib.upload_bonds(bd)
+            ib.run(2); ib.sync()
+            steps = 20
+            t0 = time.perf_counter(); ib.run(steps); ib.sync(); dt = time.perf_counter() - t0
+            acc, outp, scal = ib.fetch()
+            ne = len(b["lon"])
+            out["c4"] = {"workload": "BASELINE configs[3]: %d square-packed DEM elements (%d bond sides), MTS with 90 explicit sub-steps, dt=1800 s" % (ne, int(bd["count"].sum())),
+                         "ms_per_step": 1e3 * dt / steps, "element_substeps_per_s": ne * p.mts_sub_steps * steps / dt, "berg_steps_per_s": ne * steps / dt,
+                         "steps": steps, "error_count": float(scal[T.SCALAR_NAMES["error_count"]]),
+                         "algorithmic_bytes_per_element_substep": 256 + 104 * 4,
+                         "achieved_GBps": (256 + 104 * 4) * ne * p.mts_sub_steps * steps / dt / 1e9}
+            ib.close()
+        else:
+            out["c4"] = {"skipped": "time budget"}
+    except Exception as e:
+        out["c4"] = {"error": repr(e)}
+    out["seconds"] = time.perf_counter() - t_start
+    return out
 
 
 def main():
@@ -103,6 +181,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 rehearsal without N GPUs: every rank uses GPU 0 and the exchange goes through gloo (what is exercised is the N>1 code path, not its speed)")
     ap.add_argument("--advance-clock", action="store_true", help="kid_set_params with an advancing current_yearday before every step, as a model run does")
     ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the informational runs of configs 3 and 4 after the timed region")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=8)
     args = ap.parse_args()
@@ -162,12 +241,12 @@ def main():
         # the all-reduce (N>1) and the gather of step k run on a second stream under the per-berg kernels of step k+1;
         # slow lane: so do the general-build launches (bergs that crossed a cell edge or bounced)
         stepper = PipelinedStepper(ib, params, dist, force_collective=args.force_collective, split_general=args.split_general, slow_lane=slow_lane, resort_interval=args.resort)
-        nreduced = stepper.views[0][0].numel()
+        nreduced = stepper.views[0][0].numel() - T.NSCALAR
     else:
         acc_t = torch.zeros(count, dtype=torch.float64, device=dev)
         ib.bind_accum_buffer(acc_t.data_ptr(), count)
         stepper = ShardedStepper(ib, acc_t, ib.ncell, params.diag_mask, dist, params=params, force_collective=args.force_collective, resort_interval=args.resort)
-        nreduced = stepper.planes.numel()
+        nreduced = stepper.planes.numel() - T.NSCALAR
 
     def step():
         if args.advance_clock:
@@ -213,16 +292,24 @@ def main():
         # HBM bytes and VALU instructions per launch of the dominant kernel: PMC counters cannot be read from inside the
         # process, so these come from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_summary.json,
         # tools/profiling/run_pmc.sh) and are reported only for the population those passes were taken at
-        traffic, traffic_src, valu_per_berg_step, pmc = None, None, None, None
+        traffic, traffic_src, valu_per_berg_step, pmc, pmc_note = None, None, None, None, None
         try:
             with open(PMC_SUMMARY) as f:
-                pmc = json.load(f)["hot"]
-            if abs(pmc["grid_size_mean"] - bergs_per_launch) <= 256:
+                summary = json.load(f)
+            pmc = summary["hot"]
+            libv = ib.lib.kid_version().decode()
+            if not summary.get("complete", False):
+                pmc_note = "counter passes incomplete in " + os.path.basename(PMC_SUMMARY)
+            elif summary.get("library") != libv:
+                pmc_note = "counters were taken on another build (%s), this run is %s" % (summary.get("library"), libv)
+            elif abs(pmc["grid_size_mean"] - bergs_per_launch) > 256:
+                pmc_note = "counters were taken at another population"
+            else:
                 traffic = pmc["hbm"]["traffic_bytes_per_launch"]
-                traffic_src = "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; gfx950 fetch correction x2)"
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; gfx950 fetch correction x2)" % os.path.basename(PMC_SUMMARY)
                 valu_per_berg_step = pmc["valu_wave_instr_per_berg_step"]
-        except (OSError, KeyError, ValueError):
-            pass
+        except (OSError, KeyError, ValueError) as e:
+            pmc_note = "no PMC summary (%r)" % (e,)
         hbm_frac = achieved / HBM_PEAK_GBS
         # the other bound: one wave-instruction (fp64 included) per 4 cycles per SIMD.  instructions per berg-step x waves / time
         valu = None
@@ -230,7 +317,11 @@ def main():
             issue_s = valu_per_berg_step * (bergs_per_launch / 64.0) * 4.0 / (N_SIMD * SIMD_CLOCK_HZ)
             valu = {"wave_instr_per_berg_step": valu_per_berg_step, "floor_ms": 1e3 * issue_s, "frac": issue_s / (kern_ms * 1e-3),
                     "peak": "1 wave-instruction / 4 cycles / SIMD, %d SIMDs at %.1f GHz" % (N_SIMD, SIMD_CLOCK_HZ / 1e9),
-                    "source": "SQ_INSTS_VALU per launch / waves (profiles/r02_pmc_summary.json)"}
+                    "source": "SQ_INSTS_VALU per launch / waves (profiles/%s)" % os.path.basename(PMC_SUMMARY)}
+            clk = pmc.get("shader_clock_ghz")   # GRBM_GUI_ACTIVE / 8 XCDs / the launch's duration in the same PMC pass
+            if clk:
+                valu["shader_clock_ghz_measured"] = clk
+                valu["frac_at_measured_clock"] = valu["frac"] * (SIMD_CLOCK_HZ / 1e9) / clk
         binding = "valu_fp64_issue" if (valu and valu["frac"] > hbm_frac) else "hbm"
         line = {
             "metric": "berg_steps_per_sec", "value": value, "unit": "berg-steps/s", "n_gpus": world,
@@ -239,7 +330,7 @@ def main():
             "config": {"workload": "BASELINE configs[4] per-GPU share with configs[1] physics: %d synthetic bergs/GPU (random mass classes), 360x200 lat-lon ocean grid, "
                                    "RK4 drag+Coriolis+melt+mass spreading, dt=1800 s, ignore_traj=T" % args.bergs,
                        "bergs_per_gpu": args.bergs, "grid": "360x200", "sharding": "particle index, replicated grid",
-                       "exchange": ("RCCL all-reduce of %d per-cell planes (%.1f MB) + %d scalars per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, T.NSCALAR, ", overlapped with the next step's kernels" if pipelined else "")) if multi else "none (1 GPU)",
+                       "exchange": ("one RCCL all-reduce of %d per-cell planes (%.1f MB) + %d scalars per step%s" % (nreduced // ib.ncell, nreduced * 8 / 1e6, T.NSCALAR, ", overlapped with the next step's kernels" if pipelined else "")) if multi else "none (1 GPU)",
                        "planes_reduced_per_step": (nreduced // ib.ncell) if multi else 0, "MB_reduced_per_step": (nreduced * 8 / 1e6) if multi else 0.0,
                        "bergs_alive_at_end": n_alive},
             "library": ib.lib.kid_version().decode(),   # names the build switches (an experiment or exact-math build says so)
@@ -250,13 +341,18 @@ def main():
             "roofline": {"bound": binding, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
                          "frac_of": "hbm", "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac},
                          "valu_fp64_issue": valu,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": pmc_note,
                          "kernel": "berg_kernel<true, true, 14u, true, 1> (RK4, old interp order, evolve|thermo|spread, hot build, plain namelist)",
                          "kernel_ms_avg": kern_ms, "kernel_launches": launches, "bergs_per_launch": bergs_per_launch,
                          "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
         }
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
+        if world == 1 and not args.no_other_configs and not args.force_collective:
+            stepper = None
+            ib.close()   # (3.9 GB of berg state + the re-binning buffers: config 3 needs the room to be quick to allocate)
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
+            line["other_configs"] = other_configs(np, torch, S, T, Icebergs)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -142,7 +142,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
     keep(park_ms); keep(park_bits); keep(park_hd); keep(park_flk); keep(park_flbits); keep(park_flbergy);
     continue;
   }
-  double *scal = acc + (size_t)KID_NACC * ncell;
+  double *scal = acc - KID_NSCALAR;   // the step's scalar increments sit in front of plane 0 (kid_accum_device_ptr)
 
   // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
   Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) footloose_kernel(const DevGrid g, const k
   if (q >= cx.n) return;
   const BergPtrs &b = *bt;
   if (b.i[KID_BI_ALIVE][q] == 0) return;
-  footloose_one(g, *pp, b, cx, q, acc, ncell, acc + (size_t)KID_NACC * ncell);
+  footloose_one(g, *pp, b, cx, q, acc, ncell, acc - KID_NSCALAR);
 }
 
 // the device-side tables are rewritten by stream-ordered one-lane kernels (the new contents travel as kernel arguments):
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(256) gather_kernel(const DevGrid g, const kid_
                                                      const double *__restrict__ spread_mass_old, const double *__restrict__ spread_mass_tmp) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < KID_NSCALAR) {  // fold this step's increments into the running totals kept on `bergs` (IB:3130, 3295)
-    totals[t] += acc[(size_t)KID_NACC * ncell + t];
-    acc[(size_t)KID_NACC * ncell + t] = 0.;
+    totals[t] += (acc - KID_NSCALAR)[t];   // (the step's scalar increments sit in front of plane 0)
+    (acc - KID_NSCALAR)[t] = 0.;
   }
   const int nic = g.iec - g.isc + 1, njc = g.jec - g.jsc + 1;
   if (t >= nic * njc) return;
@@ -377,7 +377,9 @@ struct kid_handle {
   // device memory
   double *d_static[KID_NGRID_STATIC] = {}, *d_forcing[KID_NFORCING] = {};
   VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr; double *d_hotok = nullptr;
-  double *d_acc_own = nullptr, *d_acc = nullptr;  // KID_NACC*ncell + KID_NSCALAR
+  // the accumulator block: KID_NSCALAR step scalars, then KID_NACC planes of ncell (scalars first, so that they and the planes a
+  // step really fills -- a prefix -- are ONE contiguous range for the all-reduce); d_acc points at plane 0
+  double *d_acc_own = nullptr, *d_acc = nullptr;
   double *d_out = nullptr;                        // KID_NOUT*ncell
   double *d_totals = nullptr;                     // KID_NSCALAR running totals (the block's scalars are per-step)
   BergPtrs bp{};
@@ -525,8 +527,12 @@ extern "C" {
 
 // The build's arithmetic and measurement switches are part of its identity: a library built with -DKID_EXPERIMENTS (KID_EXP_*
 // measurement macros, possibly wrong answers) or -DKID_EXACT_MATH (IEEE division/sqrt/pow everywhere) says so.
+#ifndef KID_BUILD_ID
+#define KID_BUILD_ID "unknown"
+#endif
+// "src <id>": the first 12 hex digits of the SHA-1 of the library's sources (csrc/Makefile): profiles name the build they measured
 const char *kid_version(void) {
-  return "kid_hip 0.2 (gfx950)"
+  return "kid_hip 0.3 (gfx950) src " KID_BUILD_ID
 #ifdef KID_EXACT_MATH
          " exact-math"
 #endif
@@ -593,7 +599,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   const size_t accn = (size_t)KID_NACC * h->ncell + KID_NSCALAR;
   KID_HIP(h, hipMalloc(&h->d_acc_own, accn * sizeof(double)));
   KID_HIP(h, hipMemset(h->d_acc_own, 0, accn * sizeof(double)));
-  h->d_acc = h->d_acc_own;
+  h->d_acc = h->d_acc_own + KID_NSCALAR;
   KID_HIP(h, hipMalloc(&h->d_out, (size_t)KID_NOUT * h->ncell * sizeof(double)));
   KID_HIP(h, hipMemset(h->d_out, 0, (size_t)KID_NOUT * h->ncell * sizeof(double)));
   KID_HIP(h, hipMalloc(&h->d_totals, KID_NSCALAR * sizeof(double)));
@@ -1647,15 +1653,15 @@ int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalar
 }
 int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count) {
   if (!h || !dev_ptr || !count) return KID_EINVAL;
-  *dev_ptr = h->d_acc;
+  *dev_ptr = h->d_acc - KID_NSCALAR;
   *count = (int64_t)((size_t)KID_NACC * h->ncell + KID_NSCALAR);
   return KID_OK;
 }
 int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count) {
   if (!h) return KID_EINVAL;
-  if (!dev_ptr) { h->d_acc = h->d_acc_own; h->acc_prezeroed = false; return KID_OK; }
+  if (!dev_ptr) { h->d_acc = h->d_acc_own + KID_NSCALAR; h->acc_prezeroed = false; return KID_OK; }
   if (count < (int64_t)((size_t)KID_NACC * h->ncell + KID_NSCALAR)) { h->err = "accumulator buffer too small"; return KID_EINVAL; }
-  h->d_acc = (double *)dev_ptr;
+  h->d_acc = (double *)dev_ptr + KID_NSCALAR;
   h->acc_prezeroed = false;
   return KID_OK;
 }

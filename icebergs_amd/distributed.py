@@ -37,7 +37,8 @@ def needs_footprint_planes(params):
 
 
 def accumulator_views(acc_block, ncell, diag_mask=0, params=None):
-    """(planes that must be reduced, scalar increments) as views of the contiguous accumulator block."""
+    """(what must be reduced: the step's scalar increments + the planes the step fills, ONE contiguous view; the scalars alone)
+    of the accumulator block, which is laid out scalars first (include/kid.h kid_accum_device_ptr)."""
     diag_planes = sum(T.ENUMS[k] for k in (
         "KID_DIAG_MELT_BY_CLASS", "KID_DIAG_FL_PARENT_MELT", "KID_DIAG_FL_CHILD_MELT", "KID_DIAG_MELT_BUOY",
         "KID_DIAG_MELT_EROS", "KID_DIAG_MELT_CONV", "KID_DIAG_MELT_BUOY_FL", "KID_DIAG_MELT_EROS_FL",
@@ -48,7 +49,7 @@ def accumulator_views(acc_block, ncell, diag_mask=0, params=None):
         nplanes = T.ENUMS["KID_NACC_CORE"]
     else:
         nplanes = T.ENUMS["KID_A_MASS_ON_OCEAN"] + 9   # melt/heat/bits planes + the 9 mass_on_ocean slots
-    return acc_block[: nplanes * ncell], acc_block[T.NACC * ncell: T.NACC * ncell + T.NSCALAR]
+    return acc_block[: T.NSCALAR + nplanes * ncell], acc_block[: T.NSCALAR]
 
 
 def needs_spread_mass_old(params):
@@ -87,8 +88,7 @@ class ShardedStepper:
             self.backend.step_prepare(getattr(self, "_forcing", None))   # forcing prepass + accumulator zeroing, one launch
         self.backend.step_local()
         if self.dist is not None:
-            self.dist.all_reduce(self.planes)
-            self.dist.all_reduce(self.scalars)
+            self.dist.all_reduce(self.planes)      # scalars + live planes: one collective
             if self.spread_mass_old is not None:
                 self.dist.all_reduce(self.spread_mass_old)
         self.backend.step_gather()
@@ -174,9 +174,7 @@ class PipelinedStepper:
             self.new_done[cur].record(self.comm)            # behind the general-build launches of this step
             with torch.cuda.stream(self.xchg):
                 self.xchg.wait_event(self.new_done[cur])
-                planes, scalars = self.views[cur]
-                self.dist.all_reduce(planes)
-                self.dist.all_reduce(scalars)
+                self.dist.all_reduce(self.views[cur][0])   # scalars + live planes: one collective
                 ib.set_stream(self.xchg.cuda_stream)
                 ib.step_gather()
                 self.gather_done[cur].record(self.xchg)
@@ -189,9 +187,7 @@ class PipelinedStepper:
             if not self.lib_orders:
                 self.comm.wait_event(self.local_done[cur])
             if self.dist is not None:
-                planes, scalars = self.views[cur]
-                self.dist.all_reduce(planes)
-                self.dist.all_reduce(scalars)
+                self.dist.all_reduce(self.views[cur][0])   # scalars + live planes: one collective
             ib.set_stream(self.comm.cuda_stream)
             ib.step_gather()
             if not self.lib_orders:

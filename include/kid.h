@@ -250,7 +250,9 @@ int kid_run_step(kid_handle *h, int nsteps); /* nsteps x (kid_step_local; kid_st
 /* acc: KID_NACC fields, out: KID_NOUT fields, each (ied-isd+1)*(jed-jsd+1); scalars: KID_NSCALAR running totals
  * since kid_create (the reference keeps them on `bergs`). NULL skips. */
 int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalars);
-/* Device view of the accumulator block for RCCL: KID_NACC*ncell + KID_NSCALAR contiguous doubles. */
+/* Device view of the accumulator block for RCCL: KID_NSCALAR + KID_NACC*ncell contiguous doubles -- the step's scalar
+ * increments first, then the planes, so that the scalars and the planes a step fills (a prefix of the planes: distributed.py
+ * accumulator_views) are one contiguous range, one all-reduce. */
 int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count);
 /* Use caller-owned device memory (e.g. a torch tensor) for the accumulator block instead. */
 int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count);

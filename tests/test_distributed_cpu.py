@@ -40,10 +40,10 @@ def _worker(rank, world, port, nbergs, nsteps, out_dir, find_melt=0):
     mine = D.take_shard(b, rank, world)
     o = oracle_lib.Oracle(grid, p)
     ncell = o.ni * o.nj
-    # one contiguous block [planes | scalars], as the HIP handle lays it out
-    block = np.zeros(T.NACC * ncell + T.NSCALAR)
-    o.acc = block[: T.NACC * ncell].reshape(T.NACC, o.nj, o.ni)
-    o.scalars = block[T.NACC * ncell:]
+    # one contiguous block [scalars | planes], as the HIP handle lays it out (the scalars and the live planes are ONE all-reduce)
+    block = np.zeros(T.NSCALAR + T.NACC * ncell)
+    o.acc = block[T.NSCALAR:].reshape(T.NACC, o.nj, o.ni)
+    o.scalars = block[: T.NSCALAR]
     spread_old = None
     if find_melt:   # grd%spread_mass_old (+ spread_mass_tmp): two more planes the ranks sum
         spread_old = np.zeros(2 * ncell)
@@ -138,4 +138,5 @@ def test_sharded_find_melt_needs_its_planes():
     st = ShardedStepper(None, block, 16, 0, None, params=p, spread_mass_old=torch.zeros(32, dtype=torch.float64))
     assert st.spread_mass_old is not None
     planes, scalars = accumulator_views(block, 16, 0, p)
-    assert scalars.numel() == T.NSCALAR and planes.numel() % 16 == 0
+    assert scalars.numel() == T.NSCALAR and (planes.numel() - T.NSCALAR) % 16 == 0
+    assert planes.data_ptr() == scalars.data_ptr() == block.data_ptr()   # one contiguous range from the head of the block

@@ -240,7 +240,7 @@ __device__ __forceinline__ void footloose_one(const DevGrid &g, const kid_params
 // cell one, rarely two: every child pushes itself on its parent cell's list (head[cell], next[]), then counts the children of
 // that list that the reference's loop meets before it -- parents compared by the `inorder` keys (FW:4318-4359), equal keys by
 // the parent's id, one parent's two events by the event -- and takes counter + 1 + that count.
-struct FlIdCtx { int32_t *head, *next; int64_t *newid; int32_t *counter; long long n_old; int m; int iNg; };
+struct FlIdCtx { int32_t *head, *next; int64_t *newid; int32_t *counter; long long n_old; int m; int iNg, ij0; };   // iNg, ij0: kid_grid_desc gni / gi0 / gj0
 __device__ __forceinline__ void fl_event_of(const int64_t prov, long long &parent, int &ev) {
   const int64_t v = -prov - 1;
   parent = (long long)(v >> 1); ev = (int)(v & 1);
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) fl_assign_ids_rank(const DevGrid g, const
     if (fl_event_before(b, po, eo, pr, ev)) ++before;
   }
   const int32_t cnt = x.counter[cell] + 1 + before;          // generate_id: the counter is incremented, then used
-  x.newid[e] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)(pi + (x.iNg * (pj - 1)));
+  x.newid[e] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)(pi + (x.iNg * (pj - 1)) + x.ij0);
 }
 template <class BP>
 __global__ void __launch_bounds__(256) fl_assign_ids_store(const DevGrid g, const BP *bt, const FlIdCtx x) {

@@ -410,6 +410,12 @@ struct kid_handle {
   hipEvent_t evC = nullptr, evP = nullptr;
   VelRec *d_vel2 = nullptr; TrcRec *d_trc2 = nullptr; DevGrid *d_grid2 = nullptr; int forc_parity = 0;  // forcing records of the odd steps
   double *d_pkt[2] = {nullptr, nullptr};   // gathered cell packets of the hot build, one set per parity of the forcing records
+  // A/B switches for measurements and tests, read from the environment ONCE, when the handle is created (nothing on the
+  // stepping path calls getenv): KID_MTS_NO_GRAPH, KID_STABLE_RESORT, KID_NO_PLAIN_BUILD, KID_FL_UNFUSED, KID_NEW_ORDER_UNFUSED,
+  // KID_MTS_ALWAYS_LABEL, KID_MTS_NO_FUSED, KID_MTS_FUSED_BLOCKS_CAP (workgroups the fused sub-step kernel may use: tests of its
+  // fall-back), KID_MTS_POLL_LIMIT (spins before a lane of that kernel gives up: tests of the time-out)
+  struct DebugOpts { bool stable_resort = false, no_plain_build = false, fl_unfused = false, new_order_unfused = false, mts_always_label = false, mts_no_fused = false;
+                     int mts_fused_blocks_cap = 0, mts_poll_limit = 0; } dbg;
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
   unsigned fl_step = 0;                  // footloose passes so far: third counter word of the child-placement generator (kid_rng.h)
   int *d_fl_cursor = nullptr;
@@ -433,7 +439,8 @@ struct kid_handle {
   hipGraphExec_t sub_graph_exec = nullptr;  // the captured sub-step loop of evolve_icebergs_mts
   long long sub_graph_n = -1; int sub_graph_steps = 0; bool sub_graph_pair = false; double sub_graph_dt = 0.; hipStream_t sub_graph_stream = nullptr;
   bool use_graph = true;
-  int fused_blocks = 0;                     // co-resident workgroups of mts_substeps_kernel (0: not asked yet)
+  int fused_blocks[2] = {0, 0};             // co-resident workgroups of mts_substeps_kernel<4> / <8> (0: not asked yet)
+  bool fused_ran = false;                   // a fused sub-step launch since the last look at its time-out counter
   Flags flags{0, 0, 1, 0, 0};
   // trajectories (kid_traj.inc): one buffer per sampled field, grown on demand
   bool traj_on = false; kid_traj_params traj_params{}; double *d_traj_f[64] = {}; double *d_traj_day = nullptr; int64_t *d_traj_id = nullptr;
@@ -587,6 +594,11 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   h->flags.footprint = footprint_needed(h->params) ? 1 : 0;
   h->capacity = capacity;
   if (getenv("KID_MTS_NO_GRAPH")) h->use_graph = false;  // A/B switch for measurements
+  h->dbg.stable_resort = getenv("KID_STABLE_RESORT") != nullptr; h->dbg.no_plain_build = getenv("KID_NO_PLAIN_BUILD") != nullptr;
+  h->dbg.fl_unfused = getenv("KID_FL_UNFUSED") != nullptr; h->dbg.new_order_unfused = getenv("KID_NEW_ORDER_UNFUSED") != nullptr;
+  h->dbg.mts_always_label = getenv("KID_MTS_ALWAYS_LABEL") != nullptr; h->dbg.mts_no_fused = getenv("KID_MTS_NO_FUSED") != nullptr;
+  if (const char *e = getenv("KID_MTS_FUSED_BLOCKS_CAP")) h->dbg.mts_fused_blocks_cap = atoi(e);
+  if (const char *e = getenv("KID_MTS_POLL_LIMIT")) h->dbg.mts_poll_limit = atoi(e);
   KID_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   for (int k = 0; k < KID_NGRID_STATIC; ++k) { KID_HIP(h, hipMalloc(&h->d_static[k], h->ncell * sizeof(double))); KID_HIP(h, hipMemset(h->d_static[k], 0, h->ncell * sizeof(double))); }
@@ -790,12 +802,16 @@ int kid_set_stream(kid_handle *h, void *s) {
   h->stream = (hipStream_t)s;
   return KID_OK;
 }
+// the cell hash of a berg id (ij_component_of_id FW:4227-4240) on this grid: i + iNg * (j - 1) + ij0 with local i, j
+static inline int id_iNg(const kid_grid_desc &d) { return d.gni > 0 ? d.gni : d.iec - d.isc + 1; }
+static inline int id_ij0(const kid_grid_desc &d) { return d.gni > 0 ? d.gi0 + d.gni * d.gj0 : 0; }
+static int mts_check_timeout(kid_handle *h);   // kid_mts_host.inc
 int kid_sync(kid_handle *h) {
   if (!h) return KID_EINVAL;
   KID_HIP(h, hipSetDevice(h->device));
   { const int rc_j = join_side(h); if (rc_j) return rc_j; }
   KID_HIP(h, hipStreamSynchronize(h->stream));
-  return KID_OK;
+  return mts_check_timeout(h);
 }
 
 // gather the cell packets of the current parity from the record arrays (after either of them has changed)
@@ -1115,7 +1131,7 @@ static int rebin_core(kid_handle *h, bool with_lane, int *list, const int *list_
   const unsigned nb = (unsigned)((n + 255) / 256);
   const unsigned dead_key = (unsigned)h->ncell;  // larger than any cell index
   if (!h->d_key[0]) {
-    h->stable_resort = getenv("KID_STABLE_RESORT") != nullptr;  // a stable comparison sort keeps the row order inside a cell
+    h->stable_resort = h->dbg.stable_resort;  // a stable comparison sort keeps the row order inside a cell
     for (int q = 0; q < 2; ++q) {
       KID_HIP(h, hipMalloc(&h->d_key[q], (size_t)h->capacity * sizeof(unsigned)));
       KID_HIP(h, hipMalloc(&h->d_idx[q], (size_t)h->capacity * sizeof(unsigned)));
@@ -1222,7 +1238,7 @@ static bool plain_namelist(const kid_handle *h) {
 #undef KID_X
   const Flags &f = h->flags;
   return same && h->gd.grid_is_latlon && !p.pass_fields_to_ocean_model && !f.has_static && !f.has_fl && !f.store_env && !f.footprint && !f.no_diag &&
-         getenv("KID_NO_PLAIN_BUILD") == nullptr;
+         !h->dbg.no_plain_build;
 }
 template <unsigned PH>
 static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_len = -1) {   // range: the rows to step (default all)
@@ -1353,7 +1369,7 @@ static int launch_berg_lanes(kid_handle *h) {
     (void)hipEventRecord(h->evG[0], S); h->evG_live[0] = true;                                                                  \
   } while (0)
   const bool plain = plain_namelist(h);
-  const bool rebin_now = h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval && !h->have_bonds && getenv("KID_STABLE_RESORT") == nullptr;
+  const bool rebin_now = h->resort_interval > 0 && ++h->steps_since_sort >= h->resort_interval && !h->have_bonds && !h->dbg.stable_resort;
   int rebin_rc = KID_OK;
   if (rk) KID_LAUNCH_LANES(true); else KID_LAUNCH_LANES(false);
 #undef KID_LAUNCH_LANES
@@ -1424,7 +1440,7 @@ static int fl_assign_ids(kid_handle *h, long long n_old, int m) {
     KID_HIP(h, hipMalloc(&h->d_fl_next, (size_t)h->fl_ev_capacity * sizeof(int32_t)));
     KID_HIP(h, hipMalloc(&h->d_fl_newid, (size_t)h->fl_ev_capacity * sizeof(int64_t)));
   }
-  const FlIdCtx x{h->d_fl_head, h->d_fl_next, h->d_fl_newid, h->d_iceberg_counter, n_old, m, h->gd.iec - h->gd.isc + 1};
+  const FlIdCtx x{h->d_fl_head, h->d_fl_next, h->d_fl_newid, h->d_iceberg_counter, n_old, m, id_iNg(h->gd), id_ij0(h->gd)};
   const dim3 grid((unsigned)((m + 255) / 256)), block(256);
   const DevGrid g = dev_grid(h);
   hipLaunchKernelGGL(fl_assign_ids_push<BergPtrs>, grid, block, 0, h->stream, g, (const BergPtrs *)h->d_bp, x);
@@ -1534,7 +1550,7 @@ int kid_step_local(kid_handle *h) {
     if (rc) return rc;
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);
   }
-  if (p.footloose && !p.static_icebergs && getenv("KID_FL_UNFUSED") == nullptr) {
+  if (p.footloose && !p.static_icebergs && !h->dbg.fl_unfused) {
     // calving sits between evolve and thermodynamics (IB:5453): fused into the per-berg launch (PH_FL), one pass over the
     // SoA instead of three (320 B per berg-step instead of 530).  The children it appends are new rows; they
     // owe this step's thermodynamics and spreading, which a second, short launch over those rows delivers.
@@ -1606,7 +1622,7 @@ int kid_step_local(kid_handle *h) {
     // IB:5423: interpolate, evolve; IB:5473: interpolate again at the new position, then thermodynamics.  Per berg that
     // is one chain, so one launch (the second interpolation sits between the phases inside berg_kernel)
     if (lanes_eligible(h)) return launch_berg_lanes<false>(h);
-    if (!p.static_icebergs && getenv("KID_NEW_ORDER_UNFUSED") == nullptr) return launch_berg<PH_INTERP | PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
+    if (!p.static_icebergs && !h->dbg.new_order_unfused) return launch_berg<PH_INTERP | PH_EVOLVE | PH_THERMO | PH_SPREAD>(h);
     rc = p.static_icebergs ? launch_berg<PH_INTERP>(h) : launch_berg<PH_INTERP | PH_EVOLVE>(h);
     if (rc) return rc;
     rc = launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h);

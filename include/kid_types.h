@@ -26,6 +26,11 @@ typedef struct kid_grid_desc {
   int32_t isc, iec, jsc, jec;   /* computational domain      */
   int32_t grid_is_latlon;       /* FW:748 */
   int32_t grid_is_regular;      /* FW:749 */
+  /* Where this grid sits in the global one (a domain-decomposed host: one handle per tile): gni = global zonal size (icebergs_init's
+   * gni, IB:92-99), gi0 / gj0 = what must be added to a local cell index to get the global one.  They enter the cell hash of a
+   * berg id only (ij_component_of_id FW:4227-4240: i_global + gni * (j_global - 1)), so that bergs created on different tiles
+   * (calving, footloose children, ids of a 32-bit-era restart) never share an id.  gni = 0: this grid is the whole grid. */
+  int32_t gni, gnj, gi0, gj0;
   double  Lx;                   /* FW:712 zonal period; <=0 means not periodic */
 } kid_grid_desc;
 

@@ -103,7 +103,7 @@ int ko_calving(const ko_grid *g, const kid_params *p, const kid_calving_params *
   /* ---- calve_icebergs IB:6225-6402 ---- */
   for (size_t c = 0; c < KID_NCLASSES * ncell; ++c) s->real_calving[c] = 0.;                      /* IB:6253 */
   double calving_to_bergs = 0., heat_to_bergs = 0.;
-  const int iNg = iec - isc + 1;
+  const int iNg = g->d.gni > 0 ? g->d.gni : iec - isc + 1, ij0 = g->d.gni > 0 ? g->d.gi0 + g->d.gni * g->d.gj0 : 0;   /* kid_grid_desc: a tile hashes the global cell */
   for (int k = 0; k < KID_NCLASSES; ++k) for (int j = jsc; j <= jec; ++j) for (int i = isc; i <= iec; ++i) {
     const size_t c = GIDX(g, i, j);
     double ddt = 0.;
@@ -134,7 +134,7 @@ int ko_calving(const ko_grid *g, const kid_params *p, const kid_calving_params *
       { /* generate_id FW:4165-4179 */
         int32_t cnt = 1;
         if (g->iceberg_counter) { g->iceberg_counter[c] += 1; cnt = g->iceberg_counter[c]; }
-        const int32_t ij = i + (iNg * (j - 1));
+        const int32_t ij = i + (iNg * (j - 1)) + ij0;
         if (b->id) b->id[q] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)ij;
       }
       putf(b, KID_B_START_DAY, q, p->current_yearday + ddt / 86400.);

@@ -151,8 +151,8 @@ static int calve_child(const ko_grid *g, const kid_params *p, kid_berg_soa *b, i
     const int i = b->i32[KID_BI_INE][pk], j = b->i32[KID_BI_JNE][pk];
     int32_t cnt = 1;
     if (g->iceberg_counter) { g->iceberg_counter[GIDX(g, i, j)] += 1; cnt = g->iceberg_counter[GIDX(g, i, j)]; }
-    const int iNg = g->d.iec - g->d.isc + 1;
-    const int32_t ij = i + (iNg * (j - 1));
+    const int iNg = g->d.gni > 0 ? g->d.gni : g->d.iec - g->d.isc + 1, ij0 = g->d.gni > 0 ? g->d.gi0 + g->d.gni * g->d.gj0 : 0;
+    const int32_t ij = i + (iNg * (j - 1)) + ij0;
     if (b->id) b->id[c] = (int64_t)cnt * ((int64_t)1 << 32) + (int64_t)ij;
   }
   putf(b, KID_B_HALO_BERG, c, 0.0);

@@ -113,6 +113,36 @@ def test_oracle_budgets_close_over_steps():
     assert st["flags"] == [0, 1, 1]
 
 
+def test_ids_of_two_tiles_do_not_collide():
+    """two tiles of a decomposed grid calve in the same local cell: with the tiles' places in the global grid in kid_grid_desc
+    (gni, gi0, gj0) the ids hash the GLOBAL cell as ij_component_of_id does (FW:4227-4240); without them the same ids would be
+    handed out twice"""
+    ids = {}
+    for label, with_global in (("local", False), ("global", True)):
+        ids[label] = []
+        for tile in (0, 1):
+            grid, p, cp, b = _setup(n=1, ni=60, nj=200)
+            d = grid["desc"]
+            if with_global:
+                d.gni, d.gnj, d.gi0, d.gj0 = 120, 200, 60 * tile, 0          # two tiles side by side
+            orc = O.Oracle(grid, p)
+            st = orc.new_calving_state()
+            nic, njc = d.iec - d.isc + 1, d.jec - d.jsc + 1
+            calv, hflx = np.zeros((njc, nic)), np.zeros((njc, nic))
+            i, j = 17, 40
+            area = grid["static"]["area"][j - d.jsd, i - d.isd]
+            bucket = p.initial_mass_s[0] * cp.mass_scaling_s[0]
+            calv[j - d.jsc, i - d.isc] = 2.5 * bucket / (cp.distribution_s[0] * p.dt * area)
+            bergs = _with_room(b, 64)
+            rc, scal = orc.calving(cp, calv, hflx, st, bergs, 64)
+            assert rc == 0 and bergs["_n"] > 1
+            ids[label].append(set(int(v) for v in bergs["id"][1:bergs["_n"]]))
+    assert ids["local"][0] == ids["local"][1]                       # the defect: the same ids on both tiles
+    assert not (ids["global"][0] & ids["global"][1])                # the global hash keeps them apart
+    assert all((v & 0xFFFFFFFF) == 17 + 120 * (40 - 1) for v in ids["global"][0])
+    assert all((v & 0xFFFFFFFF) == (17 + 60) + 120 * (40 - 1) for v in ids["global"][1])
+
+
 def _compare_state(ref, got, label):
     for name in ("calving", "calving_hflx", "stored_ice", "stored_heat", "real_calving", "rmean_calving", "rmean_calving_hflx"):
         assert np.array_equal(got[name], ref[name]), (label, name, float(np.abs(got[name] - ref[name]).max()))
@@ -135,12 +165,15 @@ def _compare_new_bergs(rb, gb, n0, label):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["plain", "running_mean", "restarted", "stored_env"])
+@pytest.mark.parametrize("variant", ["plain", "running_mean", "restarted", "stored_env", "tile"])
 def test_calving_parity(variant):
     """planes bit-exact (pointwise arithmetic in the reference's order), new bergs bit-exact but for the in-cell position
     and the interpolated environment (1e-12), budget sums to 1e-12 (they are reductions)"""
     from icebergs_amd.framework import Icebergs
     grid, p, cp, b = _setup(n=200, tau=3.0e6 if variant == "running_mean" else 0.0, restarted=variant == "restarted", old_order=variant != "stored_env")
+    if variant == "tile":   # this grid is a tile of a larger one: the ids hash the global cell (kid_grid_desc gni, gi0, gj0)
+        d = grid["desc"]
+        d.gni, d.gnj, d.gi0, d.gj0 = 1440, 800, 360, 200
     orc = O.Oracle(grid, p)
     st = orc.new_calving_state()
     cap = 12000

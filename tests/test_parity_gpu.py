@@ -392,6 +392,46 @@ def test_c4_fused_substeps_match_three_launches(oracle, case, monkeypatch):
         assert (fusedbd["broken"] != 0).sum() > 0
 
 
+def test_c4_fused_substeps_fall_back_when_they_do_not_fit(oracle, monkeypatch):
+    """the fused sub-step kernel needs every berg's lane co-resident; a population beyond what fits (here: a cap of one workgroup,
+    KID_MTS_FUSED_BLOCKS_CAP, on 400 elements = two workgroups) must take the three-launch path by itself and give the same answer"""
+    grid, p, b, bd = S.config_c4(nx=20, ny=20, hexagonal=False, radius=1500.0, ni=45, nj=45, sub_steps=40, origin=(40137.0, 35211.0))
+    S.set_diag_all(p)
+    assert len(b["lon"]) == 400
+    fused, fusedbd = P.run_hip_mts(grid, p, b, bd, 4)
+    monkeypatch.setenv("KID_MTS_FUSED_BLOCKS_CAP", "1")
+    capped, cappedbd = P.run_hip_mts(grid, p, b, bd, 4)
+    P.compare_mts(capped, cappedbd, fused, fusedbd, "C4 fused vs capped (fall-back)")
+    monkeypatch.delenv("KID_MTS_FUSED_BLOCKS_CAP")
+    monkeypatch.setenv("KID_MTS_NO_FUSED", "1")
+    plain, plainbd = P.run_hip_mts(grid, p, b, bd, 4)
+    for f in ("lon", "lat", "uvel", "vvel", "rot"):   # the capped run IS the three-launch path: bit for bit
+        assert np.array_equal(capped[0][f], plain[0][f]), f
+
+
+def test_c4_fused_substeps_time_out_loudly(oracle, monkeypatch):
+    """a lane of the fused kernel that gives up waiting for a neighbour's record (here: a poll limit of zero spins) must not
+    leave the step half applied in silence: the rows hold a finite state and the next synchronisation returns an error that
+    names the time-out"""
+    from icebergs_amd.framework import Icebergs
+    from icebergs_amd import lib as L
+    grid, p, b, bd = S.config_c4(nx=20, ny=20, hexagonal=False, radius=1500.0, ni=45, nj=45, sub_steps=90, origin=(40137.0, 35211.0))
+    monkeypatch.setenv("KID_MTS_POLL_LIMIT", "1")
+    ib = Icebergs(grid, p, capacity=len(b["lon"]))
+    try:
+        ib.upload_bergs(b); ib.upload_bonds(bd)
+        with pytest.raises(L.KidError, match="timed out"):
+            ib.run(1)
+            ib.sync()
+            ib.run(1)      # (the time-out of a step is reported at the latest when the next one starts)
+            ib.sync()
+        got = ib.download_bergs()
+        for f in ("lon", "lat", "uvel", "vvel", "rot", "ang_vel"):
+            assert np.isfinite(got[f]).all(), f
+    finally:
+        ib.close()
+
+
 @pytest.mark.parametrize("split_general", [False, True, "slow_lane", "slow_lane_diag", "slow_lane_verlet", "slow_lane_new_order"])
 def test_pipelined_stepper_matches_plain(oracle, split_general):
     """PipelinedStepper (two accumulator blocks, exchange + gather on a second stream under the next step's kernels)

@@ -36,10 +36,11 @@ __device__ __forceinline__ void keep(double x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void keep(int32_t x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void stg(double *q, long long k, double v) { *(gdouble *)((gchar *)q + (size_t)((unsigned)k << 3)) = v; }
 __device__ __forceinline__ void stg(int32_t *q, long long k, int32_t v) { *(gint32 *)((gchar *)q + (size_t)((unsigned)k << 2)) = v; }
-// the plain build (K = 1, kid_device.hpp) is launched only with all five flags zero
+// the plain build (K = 1, kid_device.hpp) is launched only with all five flags zero; the footloose profile (K = 2) with no static
+// bergs, footloose state present, no footprint planes and the diagnostics call on (store_env as the handle says)
 template <int K> struct Fl {
-#define KID_X(name) static __device__ __forceinline__ int name(const Flags &f) { if constexpr (K == 1) return 0; else return f.name; }
-  KID_X(has_static) KID_X(has_fl) KID_X(store_env) KID_X(footprint) KID_X(no_diag)
+#define KID_X(name, k2) static __device__ __forceinline__ int name(const Flags &f) { if constexpr (K == 1) return 0; else if constexpr (K == 2) return k2; else return f.name; }
+  KID_X(has_static, 0) KID_X(has_fl, 1) KID_X(store_env, f.store_env) KID_X(footprint, 0) KID_X(no_diag, 0)
 #undef KID_X
 };
 
@@ -297,7 +298,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
     const typename CellOf<FAST>::type cellv = CellOf<FAST>::make(g, pk, d.ine, d.jne);
     // fused hot build of the plain namelist (no static bergs): every berg still active here went through the hot evolve, which
     // bails unless PkCell::hotok (no NaN in the stencils)
-    constexpr bool HOTCHECKED = FAST && (PH & PH_EVOLVE) != 0 && K == 1;
+    constexpr bool HOTCHECKED = FAST && (PH & PH_EVOLVE) != 0 && K != 0;
     if constexpr (LATE_PARK) {
       const lds_double *row = seg.val + (int)__lane_id();
       park_bits = row[5 * KID_ROW]; park_hd = row[6 * KID_ROW];
@@ -351,7 +352,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
       const bool act2 = t.alive && !skipped;
       if ((Sw<K>::add_weight_to_ocean(p) && !Sw<K>::time_average_weight(p)) || Sw<K>::find_melt_using_spread_mass(p))
         spread_mass<K>(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, d.xi, d.yj, act2, acc, ncell, seg, Fl<K>::footprint(fl) != 0,
-                       (K != 1 && b.orient) ? b.orient[kk] : p.initial_orientation);
+                       (K == 0 && b.orient) ? b.orient[kk] : p.initial_orientation);
       if (!Fl<K>::no_diag(fl)) berg_diagnostics<K>(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
     seg_flush(seg, acc, ncell);

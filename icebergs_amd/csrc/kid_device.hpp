@@ -64,16 +64,19 @@ __device__ __forceinline__ void kid_tick(int idx, int idx2 = 0) {   // idx < 0: 
 // the hot build of that namelist carries none of the other branches (code size, scalar registers).  The host picks
 // K = 1 only when every one of these switches has exactly this value (plain_namelist() in kid_hip.hip).
 // ---------------------------------------------------------------------------------------------------------
-#define KID_SWITCHES(X)                                                                                              \
-  X(old_bug_bilin, 1) X(coastal_drift, 0.) X(cdrag_grounding, 0.) X(use_new_predictive_corrective, 0)                 \
-  X(iceberg_bonds_on, 0) X(internal_bergs_for_drag, 0) X(hexagonal_icebergs, 0) X(speed_limit, 0.)                    \
-  X(override_iceberg_velocities, 0) X(use_f_plane, 0) X(use_updated_rolling_scheme, 0) X(tip_parameter, 0.)           \
-  X(use_mixed_melting, 0) X(melt_icebergs_as_ice_shelf, 0) X(set_melt_rates_to_zero, 0) X(use_operator_splitting, 1)  \
-  X(footloose, 0) X(bergy_bit_erosion_fraction, 0.) X(diag_mask, 0) X(allow_bergs_to_roll, 1)                         \
-  X(Iceberg_melt_without_decay, 0) X(grounding_fraction, 0.) X(clipping_depth, 0.) X(use_old_spreading, 1)            \
-  X(add_weight_to_ocean, 1) X(time_average_weight, 0) X(find_melt_using_spread_mass, 0) X(mts, 0) X(dem, 0)
+// K = 2: the footloose profile (tests/footloose_tests/input.nml, BASELINE config 3: Verlet on a regular Cartesian grid, footloose
+// calving with bergy bits, the corrected rolling scheme, new spreading switched off by passive mode) folded the same way.
+// X(switch, value in the plain namelist, value in the footloose profile)
+#define KID_SWITCHES(X)                                                                                                      \
+  X(old_bug_bilin, 1, 0) X(coastal_drift, 0., 0.) X(cdrag_grounding, 0., 0.) X(use_new_predictive_corrective, 0, 1)          \
+  X(iceberg_bonds_on, 0, 0) X(internal_bergs_for_drag, 0, 0) X(hexagonal_icebergs, 0, 0) X(speed_limit, 0., 0.)              \
+  X(override_iceberg_velocities, 0, 0) X(use_f_plane, 0, 1) X(use_updated_rolling_scheme, 0, 1) X(tip_parameter, 0., 0.)     \
+  X(use_mixed_melting, 0, 0) X(melt_icebergs_as_ice_shelf, 0, 0) X(set_melt_rates_to_zero, 0, 0) X(use_operator_splitting, 1, 1) \
+  X(footloose, 0, 1) X(bergy_bit_erosion_fraction, 0., 1.) X(diag_mask, 0, 0) X(allow_bergs_to_roll, 1, 1)                   \
+  X(Iceberg_melt_without_decay, 0, 0) X(grounding_fraction, 0., 0.) X(clipping_depth, 0., 0.) X(use_old_spreading, 1, 0)      \
+  X(add_weight_to_ocean, 1, 0) X(time_average_weight, 0, 0) X(find_melt_using_spread_mass, 0, 0) X(mts, 0, 0) X(dem, 0, 0)
 template <int K> struct Sw {
-#define KID_X(name, plain) static __device__ __forceinline__ auto name(const kid_params &p) -> decltype(p.name) { if constexpr (K == 1) return (decltype(p.name))(plain); else return p.name; }
+#define KID_X(name, plain, flp) static __device__ __forceinline__ auto name(const kid_params &p) -> decltype(p.name) { if constexpr (K == 1) return (decltype(p.name))(plain); else if constexpr (K == 2) return (decltype(p.name))(flp); else return p.name; }
   KID_SWITCHES(KID_X)
 #undef KID_X
 };
@@ -200,8 +203,8 @@ struct DevGrid {
   __device__ __forceinline__ int idx(int i, int j) const { return (i - isd) + (j - jsd) * ni; }
 };
 
-// the plain build (K = 1) is for lat-lon grids (grid_is_latlon is the namelist default)
-template <int K> __device__ __forceinline__ bool grid_latlon(const DevGrid &g) { if constexpr (K == 1) return true; else return g.latlon != 0; }
+// the plain build (K = 1) is for lat-lon grids (grid_is_latlon is the namelist default), the footloose profile (K = 2) for Cartesian ones
+template <int K> __device__ __forceinline__ bool grid_latlon(const DevGrid &g) { if constexpr (K == 1) return true; else if constexpr (K == 2) return false; else return g.latlon != 0; }
 
 struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; };
 
@@ -1095,12 +1098,18 @@ __device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double 
     }
   }
 }
-__device__ __noinline__ void fl_bits_dimensions(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
+template <int K = 0>
+__device__ __forceinline__ void fl_bits_dimensions_inl(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
   const double l_c = p.pi / (2. * sqrt(2.));
   const double l_w = kid_root4(FL_LW_C * p.fl_youngs * FL_B_C1 * kid_cube(thickness));
   const double l_b = l_c * l_w;
   L_fl = 3. * l_b; W_fl = l_b; T_fl = thickness;
-  rolling(p, T_fl, W_fl, L_fl);
+  rolling<K>(p, T_fl, W_fl, L_fl);
+}
+// (out of line for the cold callers; the thermodynamics of a footloose run inlines it: a call in the middle of that phase makes
+// the compiler spill what is live across it)
+__device__ __noinline__ void fl_bits_dimensions(const kid_params &p, double thickness, double &L_fl, double &W_fl, double &T_fl) {
+  fl_bits_dimensions_inl<0>(p, thickness, L_fl, W_fl, T_fl);
 }
 
 // IB:3492-3785 find_basal_melt (cold: only with melt_icebergs_as_ice_shelf / use_mixed_melting)

@@ -1233,12 +1233,22 @@ static int refresh_tables(kid_handle *h);
 static bool plain_namelist(const kid_handle *h) {
   const kid_params &p = h->params;
   bool same = true;
-#define KID_X(name, plain) same = same && (p.name == (decltype(p.name))(plain));
+#define KID_X(name, plain, flp) same = same && (p.name == (decltype(p.name))(plain));
   KID_SWITCHES(KID_X)
 #undef KID_X
   const Flags &f = h->flags;
   return same && h->gd.grid_is_latlon && !p.pass_fields_to_ocean_model && !f.has_static && !f.has_fl && !f.store_env && !f.footprint && !f.no_diag &&
          !h->dbg.no_plain_build;
+}
+// ... and K = 2 with the footloose profile's (Cartesian grid, footloose state, no static bergs, no footprint planes)
+static bool fl_profile_namelist(const kid_handle *h) {
+  const kid_params &p = h->params;
+  bool same = true;
+#define KID_X(name, plain, flp) same = same && (p.name == (decltype(p.name))(flp));
+  KID_SWITCHES(KID_X)
+#undef KID_X
+  const Flags &f = h->flags;
+  return same && !h->gd.grid_is_latlon && !p.pass_fields_to_ocean_model && !f.has_static && f.has_fl && !f.footprint && !f.no_diag && !h->dbg.no_plain_build;
 }
 template <unsigned PH>
 static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_len = -1) {   // range: the rows to step (default all)
@@ -1262,6 +1272,7 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
   // stream is already in the hot build of the other half (or of the next step): the ~85 us single-wave latency of the
   // general build leaves the critical path.  Events order a half's hot build behind its own previous general build.
   const bool plain = plain_namelist(h);   // the hot build of the default namelist carries none of the other branches
+  const bool flprof = fl_profile_namelist(h);   // ... nor does the one of the footloose profile
   const int nparts = (h->pipelined && !h->params.mts && !h->params.footloose && h->n >= 4096 && range_len < 0) ? 2 : 1;
   const long long half = ((h->n / 2 + 255) / 256) * 256;
   for (int part = 0; part < nparts; ++part) {
@@ -1282,6 +1293,8 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
   do {                                                                                                                          \
     if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                       \
       hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    else if (PH == (PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD) && !RKV && !OLDV && flprof)                           \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD) && !RKV && !OLDV) ? 2 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     else                                                                                                                        \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     if (h->profile) { (void)hipEventRecord(e1, h->stream); h->pending.emplace_back(e0, e1); h->berg_launches++; } /* the timed kernel is the hot build (pass 1) */ \

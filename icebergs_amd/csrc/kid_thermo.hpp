@@ -287,7 +287,7 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   // footloose bits IB:3031-3068
   double Lfl = 0, Wfl = 0, Tfl = 0, Tnfl = 0, Lnfl = 0, Wnfl = 0, Mnew_fl, dMfl = 0., dMb_fl = 0., dMv_fl = 0., dMe_fl = 0.;
   if (has_fl) {
-    fl_bits_dimensions(p, T, Lfl, Wfl, Tfl);
+    fl_bits_dimensions_inl<K>(p, T, Lfl, Wfl, Tfl);
     const double Mfl = b.mass_of_fl_bits, Volfl = Lfl * Wfl * Tfl;
     const double Mb_fl = dmax(kid_mul_rpow5(0.58 * dvo08 * (SST + 4.0), Lfl), 0.) * perday;
     Tnfl = dmax(Tfl - Mb_fl * dt, 0.);

@@ -1686,6 +1686,11 @@ int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count) {
   *count = (int64_t)((size_t)KID_NACC * h->ncell + KID_NSCALAR);
   return KID_OK;
 }
+int kid_accum_live_count(kid_handle *h, int64_t *count) {
+  if (!h || !count) return KID_EINVAL;
+  *count = (int64_t)((size_t)nacc_active(h) * h->ncell + KID_NSCALAR);
+  return KID_OK;
+}
 int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count) {
   if (!h) return KID_EINVAL;
   if (!dev_ptr) { h->d_acc = h->d_acc_own + KID_NSCALAR; h->acc_prezeroed = false; return KID_OK; }

@@ -30,7 +30,7 @@ module kid_hip_mod
   public :: kid_thermodynamics, kid_create_gridded_icebergs_fields, kid_step_local, kid_step_gather, kid_run_step
   public :: kid_get_accumulators, kid_last_error_f, kid_check
   ! every entry point of include/kid.h is usable from Fortran (tests/test_abi.py checks the list against the header)
-  public :: kid_bond_soa, kid_accum_device_ptr, kid_bind_accum_buffer, kid_bind_spread_mass_old, kid_download_bonds
+  public :: kid_bond_soa, kid_accum_device_ptr, kid_accum_live_count, kid_bind_accum_buffer, kid_bind_spread_mass_old, kid_download_bonds
   public :: kid_evolve_icebergs_interactive, kid_evolve_icebergs_mts, kid_footloose_uniform, kid_get_iceberg_counter
   public :: kid_last_error, kid_last_redo_count, kid_move_berg_between_cells, kid_num_bond_traj_records
   public :: kid_num_traj_records, kid_profile_enable, kid_profile_get, kid_restart_count_bergs
@@ -232,6 +232,11 @@ module kid_hip_mod
       import :: c_int, c_ptr, c_int64_t
       type(c_ptr), value :: h
       type(c_ptr), intent(out) :: dev_ptr
+      integer(c_int64_t), intent(out) :: count
+    end function
+    integer(c_int) function kid_accum_live_count(h, count) bind(C, name='kid_accum_live_count')
+      import :: c_int, c_ptr, c_int64_t
+      type(c_ptr), value :: h
       integer(c_int64_t), intent(out) :: count
     end function
     integer(c_int) function kid_bind_accum_buffer(h, dev_ptr, count) bind(C, name='kid_bind_accum_buffer')

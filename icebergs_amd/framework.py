@@ -428,6 +428,12 @@ class Icebergs:
         self._check(self.lib.kid_accum_device_ptr(self.h, C.byref(p), C.byref(n)), "kid_accum_device_ptr")
         return p.value, n.value
 
+    def accum_live_count(self):
+        """doubles from the start of the accumulator block that a sharded run sums across GPUs (include/kid.h)"""
+        n = C.c_int64()
+        self._check(self.lib.kid_accum_live_count(self.h, C.byref(n)), "kid_accum_live_count")
+        return n.value
+
     def bind_accum_buffer(self, ptr, count):
         self._check(self.lib.kid_bind_accum_buffer(self.h, C.c_void_p(ptr), int(count)), "kid_bind_accum_buffer")
 

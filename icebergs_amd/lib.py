@@ -17,7 +17,7 @@ SYMBOLS = [
     "kid_sizeof", "kid_set_static_grid", "kid_set_forcing", "kid_set_forcing_device", "kid_upload_bergs", "kid_download_bergs",
     "kid_num_bergs", "kid_compact_bergs", "kid_move_berg_between_cells", "kid_set_resort_interval", "kid_zero_accumulators", "kid_interp_gridded_fields_to_bergs",
     "kid_evolve_icebergs", "kid_footloose_calving", "kid_set_footloose_step", "kid_get_footloose_step", "kid_footloose_uniform", "kid_thermodynamics", "kid_create_gridded_icebergs_fields",
-    "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr",
+    "kid_set_store_environment", "kid_set_iceberg_counter", "kid_get_iceberg_counter", "kid_step_local", "kid_step_gather", "kid_run_step", "kid_get_accumulators", "kid_accum_device_ptr", "kid_accum_live_count",
     "kid_bind_accum_buffer", "kid_bind_spread_mass_old", "kid_profile_enable", "kid_profile_get",
     "kid_last_redo_count", "kid_set_side_stream", "kid_step_prepare", "kid_upload_bonds", "kid_download_bonds", "kid_evolve_icebergs_mts", "kid_set_conglom_ids", "kid_evolve_icebergs_interactive",
     "kid_ingest_forcing", "kid_get_forcing",
@@ -127,6 +127,7 @@ def load():
     lib.kid_get_iceberg_counter.argtypes = [H, C.POINTER(C.c_int32)]
     lib.kid_get_accumulators.argtypes = [H, dp, dp, dp]
     lib.kid_accum_device_ptr.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.kid_accum_live_count.argtypes = [H, C.POINTER(C.c_int64)]
     lib.kid_bind_accum_buffer.argtypes = [H, C.c_void_p, C.c_int64]
     lib.kid_bind_spread_mass_old.argtypes = [H, C.c_void_p, C.c_int64]
     lib.kid_profile_enable.argtypes = [H, C.c_int]

@@ -254,6 +254,10 @@ int kid_get_accumulators(kid_handle *h, double *acc, double *out, double *scalar
  * increments first, then the planes, so that the scalars and the planes a step fills (a prefix of the planes: distributed.py
  * accumulator_views) are one contiguous range, one all-reduce. */
 int kid_accum_device_ptr(kid_handle *h, void **dev_ptr, int64_t *count);
+/* How many doubles from the start of that block one step fills under the current parameters (the scalar increments + the
+ * planes that are zeroed, scattered into and read by the gather): what a sharded run sums across GPUs between
+ * kid_step_local and kid_step_gather.  MPI hosts: MPI_Allreduce(MPI_IN_PLACE, dev_ptr, live_count, MPI_DOUBLE, MPI_SUM). */
+int kid_accum_live_count(kid_handle *h, int64_t *count);
 /* Use caller-owned device memory (e.g. a torch tensor) for the accumulator block instead. */
 int kid_bind_accum_buffer(kid_handle *h, void *dev_ptr, int64_t count);
 /* find_melt_using_spread_mass (IB:5490-5503): grd%spread_mass_old -- the gridded mass before the thermodynamics -- and, with

@@ -346,6 +346,32 @@ def main():
                          "kernel_ms_avg": kern_ms, "kernel_launches": launches, "bergs_per_launch": bergs_per_launch,
                          "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP},
         }
+        # The headline runs the way config 2 is configured (ignore_traj=T: berg%uo..hi are not stored back, IB:2890-2894 has no
+        # reader).  A host that samples trajectories, prints bergs_chksum or migrates bergs needs those 11 members: the same
+        # population with the store on (the K=0 build: namelist switches read at run time) -- informational, not `value`.
+        line["roofline"]["store_environment"] = False
+        if world == 1 and not args.force_collective:
+            ib.set_store_environment(True)
+            for _ in range(2):
+                step()
+            fence()
+            ib.profile(True)
+            t1 = time.perf_counter()
+            nst = max(2, min(args.steps, 10))
+            for _ in range(nst):
+                step()
+            fence()
+            el1 = time.perf_counter() - t1
+            bms, bl, _ = ib.profile_get()
+            ib.profile(False)
+            ib.set_store_environment(False)
+            k_ms = bms / max(bl, 1)
+            per_launch = args.bergs * nst / max(bl, 1)
+            line["roofline"]["with_store_environment"] = {
+                "ms_per_step": 1e3 * el1 / nst, "value": args.bergs * nst / el1, "kernel_ms_avg": k_ms, "steps": nst,
+                "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP + 11 * 8,
+                "frac": ((ALGO_BYTES_PER_BERG_STEP + 11 * 8) * per_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
+                "note": "berg%uo,vo,ui,vi,ua,va,ssh_x,ssh_y,sst,cn,hi stored every step (IB:2890-2894): +88 B per berg-step, the run-time-namelist build of the kernel"}
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         if world == 1 and not args.no_other_configs and not args.force_collective:

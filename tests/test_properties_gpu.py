@@ -4,6 +4,7 @@ needs ~1 s per 1e6 berg-steps, these run 1e6 bergs / 5e4 DEM elements).
 * melt budget: what the bergs lose (mass + bergy bits, times mass_scaling) in a step is what the per-cell
   floating_melt field receives (thermodynamics IB:3114-3117 closes this budget berg by berg);
 * order independence: re-binning every step, never, or starting from a shuffled population gives the same bergs;
+* both at the size and settings of the headline bench line (1e7 bergs of config 2, the plain hot build);
 * config 3 at its full size (1e7 bergs, the footloose profile with displaced children, zonally periodic channel): the mass
   budget closes with the footloose bits in it, ids are unique, every child drew exactly one value of its parent cell's
   counter and was counted once;
@@ -120,6 +121,54 @@ def test_results_do_not_depend_on_the_row_order_at_1e6():
             assert np.array_equal(ref[f], got[f]), f          # per-berg arithmetic does not see the order at all
         scale = np.abs(ref_out[0]).max()
         assert np.abs(got_out[0] - ref_out[0]).max() <= 1.0e-11 * scale   # per-cell sums: summation order only
+
+
+def test_config2_properties_at_the_bench_size_1e7():
+    """The population, physics and library settings of the headline bench line (bench.py: config_c2(n=1e7, seed=2),
+    kid_set_store_environment off -> the plain hot build of the fused RK4 kernel): the melt budget closes over the step, and
+    the same bergs handed over in another row order and re-binned every step come out bit for bit the same, berg by berg."""
+    n = 10_000_000
+    grid, p, b = S.config_c2(n=n, seed=2)
+    area = grid["static"]["area"]
+    keep = ("id", "alive", "lon", "lat", "uvel", "vvel", "mass", "thickness", "width", "length", "mass_of_bits", "mass_scaling", "ine", "jne")
+
+    def run(bergs, interval):
+        ib = Icebergs(grid, p, capacity=n)
+        try:
+            ib.upload_bergs(bergs)
+            ib.set_store_environment(False)
+            ib.set_resort_interval(interval)
+            ib.run(2)
+            before = ib.download_bergs()
+            m_before = before["mass_scaling"] * (before["mass"] + before["mass_of_bits"])
+            alive_before, id_before = before["alive"] != 0, before["id"].copy()
+            del before
+            ib.run(1)
+            acc, out, scal = ib.fetch()
+            after = ib.download_bergs()
+            after = {k: after[k] for k in keep}
+            return m_before, alive_before, id_before, after, acc[T.ACC_NAMES["floating_melt"]].copy(), out[0].copy()
+        finally:
+            ib.close()
+
+    m_before, alive_before, id_before, after, melt, out0 = run(b, 0)
+    assert np.array_equal(id_before, after["id"])                       # interval 0: rows stayed put
+    lost = np.where(alive_before, m_before - after["mass_scaling"] * (after["mass"] + after["mass_of_bits"]), 0.0)
+    total_lost, received = float(np.sum(lost)), float(np.sum(melt * area)) * p.dt
+    assert total_lost > 0.0 and abs(received - total_lost) <= 1.0e-9 * total_lost, (received, total_lost)
+    del m_before, alive_before, id_before, lost
+    perm = np.random.default_rng(1).permutation(n)
+    shuffled = {k: (np.ascontiguousarray(v[perm]) if hasattr(v, "dtype") else v) for k, v in b.items()}
+    del b, perm
+    _, _, _, after2, melt2, out2 = run(shuffled, 1)
+    del shuffled
+    a1, a2 = after["alive"] != 0, after2["alive"] != 0
+    assert int(a1.sum()) == int(a2.sum()) > 0.99 * n
+    o1, o2 = np.argsort(after["id"][a1], kind="stable"), np.argsort(after2["id"][a2], kind="stable")
+    for f in keep:
+        assert np.array_equal(after[f][a1][o1], after2[f][a2][o2]), f       # per-berg arithmetic does not see the order at all
+    assert np.abs(melt2 - melt).max() <= 1.0e-11 * np.abs(melt).max()       # per-cell sums: summation order only
+    assert np.abs(out2 - out0).max() <= 1.0e-11 * np.abs(out0).max()
 
 
 def test_dem_momentum_is_conserved_at_5e4_elements():

@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 rehearsal without N GPUs: every rank uses GPU 0 and the exchange goes through gloo (what is exercised is the N>1 code path, not its speed)")
     ap.add_argument("--advance-clock", action="store_true", help="kid_set_params with an advancing current_yearday before every step, as a model run does")
     ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the informational runs of configs 3 and 4 after the timed region")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline only: skip the informational runs after the timed region (store-on figure, configs 3 and 4)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=8)
     args = ap.parse_args()
@@ -350,7 +350,7 @@ def main():
         # reader).  A host that samples trajectories, prints bergs_chksum or migrates bergs needs those 11 members: the same
         # population with the store on (the K=0 build: namelist switches read at run time) -- informational, not `value`.
         line["roofline"]["store_environment"] = False
-        if world == 1 and not args.force_collective:
+        if world == 1 and not args.force_collective and not args.no_other_configs:
             ib.set_store_environment(True)
             for _ in range(2):
                 step()

@@ -74,8 +74,22 @@ struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;   
 #else
 #define KID_NUM_VGPR_ATTR
 #endif
+// The plain hot build of the fused RK4 step (BASELINE configs 1-2 and the headline line) runs THREE waves per SIMD: with the four
+// stages unrolled it needs 174 registers (the rolled loop 203: the stage-dependent selects and the loop-carried copies), six of
+// them spilled at the 168 a third wave allows; and its LDS fits twelve times into a CU (160 KB in 1280-byte blocks: 12800 bytes
+// per wave) with KID_HOT3_SLOTS cell packets and KID_HOT3_CHUNK staging rows.  Measured at 1e7 bergs: 0.98 -> 0.88 ms per launch.
+template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg {
+#if defined(KID_EXACT_MATH) || defined(KID_EXP_NO_HOT3)
+  static constexpr bool three = false;
+#else
+  static constexpr bool three = FAST && RK && OLD_ORDER && K == 1 && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
+#endif
+  static constexpr int slots = three ? 12 : KID_MAXRUN;   // cell packets per wave
+  static constexpr int chunk = three ? 10 : KID_CHUNK;    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
+  static constexpr int waves = !FAST ? KID_GENERAL_WAVES_PER_EU : (three ? 3 : KID_WAVES_PER_EU);
+};
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K = 0>
-__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAST ? KID_WAVES_PER_EU : KID_GENERAL_WAVES_PER_EU) berg_kernel(const DevGrid *__restrict__ gtab, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
+__global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (HotCfg<RK, OLD_ORDER, PH, FAST, K>::waves)) berg_kernel(const DevGrid *__restrict__ gtab, const kid_params *__restrict__ pp, const BergPtrs *__restrict__ bt, const long long n,
                                                    double *__restrict__ acc, const size_t ncell, const Flags fl, const Redo redo) {
   // The parameter block (142 dwords) and the 51 field pointers are read through device-memory tables on demand:
   // as by-value kernel arguments they were all pinned in SGPRs, overflowed the scalar file and came back as
@@ -85,9 +99,11 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
   const DevGrid &g = *gtab;   // like the other two tables: read on demand, not pinned in ~50 SGPRs for the whole kernel
   constexpr bool SCATTER = (PH & (PH_THERMO | PH_SPREAD)) != 0;
   constexpr int WG_WAVES = FAST ? KID_HOT_WG / 64 : 4;   // (the general build is launched one wave per workgroup; its other entry points with up to four)
-  __shared__ double lds_vals[SCATTER ? seg_lds_doubles(WG_WAVES) : 1];   // staging of the per-cell sums (kid_thermo.hpp)
-  __shared__ int lds_ints[seg_lds_ints(WG_WAVES)];                         // run tables of the workgroup's waves
-  __shared__ __attribute__((aligned(16))) double lds_pk[FAST ? WG_WAVES * KID_MAXRUN * PK_STRIDE : 2];   // cell packets of the workgroup's waves (hot build)
+  using Cfg = HotCfg<RK, OLD_ORDER, PH, FAST, K>;
+  constexpr int SLOTS = Cfg::slots, CHUNK = Cfg::chunk;
+  __shared__ double lds_vals[SCATTER ? seg_lds_doubles(WG_WAVES, CHUNK) : 1];   // staging of the per-cell sums (kid_thermo.hpp)
+  __shared__ int lds_ints[seg_lds_ints(WG_WAVES, CHUNK)];                         // run tables of the workgroup's waves
+  __shared__ __attribute__((aligned(16))) double lds_pk[FAST ? WG_WAVES * SLOTS * PK_STRIDE : 2];   // cell packets of the workgroup's waves (hot build)
   // FAST: one pass over all bergs.  General: grid-stride over the (short) redo list.
   const long long total = FAST ? redo.klen : (long long)(*redo.count);
   const long long bdim = FAST ? (long long)KID_HOT_WG : (long long)blockDim.x;   // the general build is launched with one wave per workgroup
@@ -96,6 +112,10 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
   long long tid = (long long)blockIdx.x * bdim + threadIdx.x;
   for (bool first = true; FAST ? first : (tid - threadIdx.x < total); first = false, tid += (long long)gridDim.x * bdim) {
   KID_TICK(-1);
+  // The wave that is fetching issues first: its loads, the run table and the packet DMA are a few hundred instructions that would
+  // otherwise take turns with the other wave's arithmetic, and every cycle they finish earlier is a cycle of memory latency that
+  // overlaps with that arithmetic (measured at 1e7 bergs: 1.033 -> 1.016 ms per launch with the flush below)
+  if (FAST) __builtin_amdgcn_s_setprio(3);
   const bool inrange = tid < total;
   const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
@@ -137,6 +157,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
   }
   bool was_alive = inrange && (alive_v != 0);
   if (FAST && redo.lane) { if (was_alive && lane_v >= redo.step) was_alive = false; }
+  KID_TICK(11);   // (the wait for `alive` / the lane stamp: the first round trip)
   if (__ballot(was_alive) == 0ull) {  // wave-uniform; every other lane stays to the end (wave-level sums below)
     keep(d.ine); keep(d.jne); keep(d.xi); keep(d.yj); keep(d.lon); keep(d.lat); keep(d.uvel); keep(d.vvel); keep(d.axn); keep(d.ayn);
     keep(d.bxn); keep(d.byn); keep(t.M); keep(t.T); keep(t.W); keep(t.L); keep(t.n_bonds); keep(t.static_berg);
@@ -146,47 +167,51 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
   double *scal = acc - KID_NSCALAR;   // the step's scalar increments sit in front of plane 0 (kid_accum_device_ptr)
 
   // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
-  Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints);
+  Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
   const lds_double *pk = nullptr;
   if (FAST) {
-    lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (KID_MAXRUN * PK_STRIDE);
+    lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (SLOTS * PK_STRIDE);
     const int lane = (int)__lane_id();
     const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const int myrun = __popcll(seg.heads & le) - 1;
-    // There are packets for KID_MAXRUN distinct cells per wave.  As the cell order decays between two re-binnings a
-    // wave collects out-of-place bergs, each a run of its own: the lanes of the runs beyond the KID_MAXRUN-th go to the
-    // general build one by one (handing over the whole wave made 15 % of the population take the slow path by the end
-    // of a 16-step interval).
-    if (myrun >= KID_MAXRUN) {
+    // One packet slot per DISTINCT cell of the wave's runs.  As the cell order decays between two re-binnings a wave collects
+    // out-of-place bergs, each a run of its own that also splits the run it sits in: a slot per run staged the same packet
+    // again and again and ran out of slots two thirds into a 16-step interval (runs ~ 1.5 + 1.3 per step at 139 bergs per
+    // cell), although the bergs of a tile only ever spread over the handful of cells around where they were binned.
+    // The packets go from memory straight into LDS (gfx950: global_load_lds_dwordx4, 16 bytes per lane, lane l to LDS base + 16 l):
+    // one instruction per cell with the first 34 lanes moves the 544-byte packet, no staging registers, and every cell's load is
+    // in flight before the single wait.  The cell of a slot is wave-uniform (a v_readlane): scalar address arithmetic.
+    const gchar *gp = (const gchar *)g.pkt;
+    static_assert(PK_SIZE * 8 == 34 * 16 && (PK_STRIDE * 8) % 16 == 0 && (PK_GSTRIDE * 8) % 16 == 0, "packet = 34 lanes x 16 bytes, 16-byte aligned slots");
+    const int rc = (lane < seg.R) ? seg.cell[lane] : -1;   // lane r < R: the cell of run r (-1: a run of dead lanes)
+    const unsigned loff = (unsigned)lane * 16u;
+    unsigned long long rem = __ballot(rc >= 0);
+    int slot_of_run = 0, nslot = 0;
+    while (rem != 0ull) {  // wave-uniform: one turn per distinct cell
+      const int u = (int)__ffsll((long long)rem) - 1;
+      const int cu = __builtin_amdgcn_readlane(rc, u);
+      const bool mine = rc == cu;
+      if (mine) slot_of_run = nslot;
+      if (nslot < SLOTS && lane < 34)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)cu * (size_t)(PK_GSTRIDE * 8) + loff),
+                                         (__attribute__((address_space(3))) void *)(wpk + nslot * PK_STRIDE), 16, 0, 0);
+      rem &= ~__ballot(mine);
+      ++nslot;
+    }
+    const int myslot = __shfl(slot_of_run, myrun < 0 ? 0 : myrun);
+    // more distinct cells than slots: the lanes of the cells beyond go to the general build one by one (handing over the whole
+    // wave made 15 % of the population take the slow path by the end of a 16-step interval)
+    if (myslot >= SLOTS) {
       if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
       was_alive = false;
     }
-    if (__ballot(was_alive) == 0ull) continue;
-    const int nstage = seg.R < KID_MAXRUN ? seg.R : KID_MAXRUN;
-    // lane q fetches packet elements q and q+64 of every distinct cell from the gathered packets (DevGrid::pkt)
-    // Eight cells at a time, all their loads issued before the first LDS write: written one cell per iteration every packet
-    // was a memory round trip of its own (the write waits for its load) -- 13 in a row for a wave of config 3's sparse
-    // population (5 bergs per cell), 58 % of that wave's lifetime (tools/profiling/time_segments_c3.py), and the reason the
-    // kernel slowed down as the cell order decayed between re-binnings.  (A run without a cell loads cell 0's packet and
-    // does not store it.)
-    // The packets go from memory straight into LDS (gfx950: global_load_lds_dwordx4, 16 bytes per lane, lane l to LDS base + 16 l):
-    // one instruction per cell with the first 34 lanes moves the 544-byte packet, no staging registers, and every cell's load is
-    // in flight before the single wait.  The cell of a run is wave-uniform (one LDS read, a v_readlane per run): scalar address
-    // arithmetic, and runs that do not exist cost nothing (the unrolled register staging it replaces issued the loads of eight
-    // cells whatever the wave held -- ~10 vector instructions per slot).
-    const gchar *gp = (const gchar *)g.pkt;
-    static_assert(PK_SIZE * 8 == 34 * 16 && (PK_STRIDE * 8) % 16 == 0 && (PK_GSTRIDE * 8) % 16 == 0, "packet = 34 lanes x 16 bytes, 16-byte aligned slots");
-    const int mycell = seg.cell[lane < KID_MAXRUN ? lane : 0];
-    const unsigned loff = (unsigned)lane * 16u;
-    for (int u = 0; u < nstage; ++u) {  // wave-uniform
-      const int cu = __builtin_amdgcn_readlane(mycell, u);
-      if (cu >= 0 && lane < 34)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)cu * (size_t)(PK_GSTRIDE * 8) + loff),
-                                         (__attribute__((address_space(3))) void *)(wpk + u * PK_STRIDE), 16, 0, 0);
-    }
+    __builtin_amdgcn_s_setprio(0);
+    KID_TICK(12);   // (runs found, packet loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    pk = wpk + (myrun < KID_MAXRUN ? myrun : 0) * PK_STRIDE;
+    KID_TICK(13);   // (everything has arrived)
+    if (__ballot(was_alive) == 0ull) continue;
+    pk = wpk + (myslot < SLOTS ? myslot : 0) * PK_STRIDE;
   }
   t.alive = was_alive;   // (after the hot build has handed the lanes of its surplus runs to the general build)
   if constexpr (PARK) {
@@ -355,6 +380,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, FAS
                        (K == 0 && b.orient) ? b.orient[kk] : p.initial_orientation);
       if (!Fl<K>::no_diag(fl)) berg_diagnostics<K>(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
+    if (FAST) __builtin_amdgcn_s_setprio(3);   // ... and the wave that is about to retire: its slot goes to a wave that starts fetching
     seg_flush(seg, acc, ncell);
     KID_MARK("spread_done"); KID_TICK(9);
   }

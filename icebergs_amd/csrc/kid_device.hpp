@@ -947,7 +947,13 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
   double lon_s = lon1, lat_s = lat1, uvel_s = uvel1, vvel_s = vvel1, xdot_s = xdot1, ydot_s = ydot1;
   int i = i1, j = j1; double xi = xi1, yj = yj1;
   double s_lat1 = 0., c_lat1 = 1.;
+  // hot build: the four stages unrolled -- `s` is a constant in each copy (no stage selects, no loop-carried copies: 203 -> 174
+  // registers); the general build keeps one copy of the body
+#if defined(KID_EXACT_MATH) || defined(KID_EXP_RK_ROLLED)
 #pragma unroll 1
+#else
+#pragma unroll (FAST ? 4 : 1)
+#endif
   for (int s = 0; s < 4; ++s) {
     KID_MARK("loop_top"); KID_TICK(s == 0 ? 0 : 5);
     if (s > 0) { i = i1; j = j1; xi = xi1; yj = yj1; adjust_index_and_ground<FAST, K, HAVE_RI>(g, p, pk, lon_s, lat_s, i, j, xi, yj, err, bail, ri); }  // IB:7430-7431

@@ -45,21 +45,23 @@ struct Seg {
   int R;             // number of runs in this wave
   unsigned M;        // ceil(65536 / R): item / R == (item * M) >> 16 for item < 1024
   int npend;         // staged slots (wave-uniform)
+  int chunk;         // staged slots per flush (KID_CHUNK; fewer in the builds that trade staging rows for a third wave per SIMD)
 };
 // LDS a workgroup of `waves` waves needs for its Seg tables
-constexpr int seg_lds_doubles(int waves) { return waves * KID_CHUNK * KID_ROW + 4; }
-constexpr int seg_lds_ints(int waves) { return waves * (3 * 64 + KID_CHUNK); }
+constexpr int seg_lds_doubles(int waves, int chunk = KID_CHUNK) { return waves * chunk * KID_ROW + 4; }
+constexpr int seg_lds_ints(int waves, int chunk = KID_CHUNK) { return waves * (3 * 64 + chunk); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
-__device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *ints) {
+__device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *ints, int chunk = KID_CHUNK) {
   Seg s;
   const int lane = (int)__lane_id(), wave = (int)(threadIdx.x >> 6);
-  s.val = vals + wave * (KID_CHUNK * KID_ROW);
-  lds_int *base = ints + wave * (3 * 64 + KID_CHUNK);
+  s.chunk = chunk;
+  s.val = vals + wave * (chunk * KID_ROW);
+  lds_int *base = ints + wave * (3 * 64 + chunk);
   s.head = base; s.len = base + 64; s.cell = base + 128; s.plane = base + 192;
   const int prev = __shfl_up(key, 1);
   const bool is_head = (lane == 0) || (prev != key);
@@ -137,7 +139,7 @@ __device__ __forceinline__ void cell_add(double *acc, size_t ncell, int plane, i
   s.val[s.npend * KID_ROW + (int)__lane_id()] = active ? v : 0.0;
   s.plane[s.npend] = plane;
   s.npend += 1;
-  if (s.npend == KID_CHUNK) seg_flush(s, acc, ncell);
+  if (s.npend == s.chunk) seg_flush(s, acc, ncell);
 }
 
 // one out-of-line copy of ocml's pow (about 3 KB of code per inlined call site)

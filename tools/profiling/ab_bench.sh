@@ -5,7 +5,7 @@ mkdir -p $out
 for so in "$@"; do
   name=$(basename $so .so)
   if [ "$so" = "default" ]; then unset KID_HIP_SO; else export KID_HIP_SO=$PWD/$so; fi
-  python bench.py --no-cpu-baseline --steps 48 --warmup 12 > $out/$name.json 2> $out/$name.err || echo "FAILED $name" >> $out/summary.txt
+  python bench.py --no-cpu-baseline --no-other-configs --steps 48 --warmup 12 > $out/$name.json 2> $out/$name.err || echo "FAILED $name" >> $out/summary.txt
   python - $out/$name.json $name >> $out/summary.txt <<'PY'
 import json,sys
 try:

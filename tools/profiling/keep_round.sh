@@ -1,10 +1,10 @@
 #!/bin/bash
 # copies the summaries of the last run_round.sh from gpurun_out/ into profiles/ under the round's prefix:  keep_round.sh r02
 cd "$(dirname "$0")/../.."
-P=${1:-r02}
+P=${1:-r03}
 tail -1 gpurun_out/bench_round.log > profiles/${P}_bench_line.json
 cp gpurun_out/round_kernel_stats.csv profiles/${P}_bench_kernel_stats.csv
-cp gpurun_out/round_pmc_summary.json profiles/${P}_pmc_summary.json
+python3 -c "import json,sys; sys.exit(0 if json.load(open('gpurun_out/round_pmc_summary.json')).get('complete') else 1)" && cp gpurun_out/round_pmc_summary.json profiles/${P}_pmc_summary.json
 # the HBM bytes of the hot build alone, under the name the reviews ask for
 python3 - profiles/${P}_pmc_summary.json profiles/${P}_hbm_traffic.json <<'PY'
 import json, sys

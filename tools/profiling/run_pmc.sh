@@ -3,7 +3,7 @@
 # Each --pmc pass is its own run with --kernel-trace only.  Summaries: tools/profiling/pmc_summary.py
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline $@"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-other-configs $@"
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM" \

@@ -11,11 +11,11 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_c3_$i -- python3 $R/tools/profiling/bench_c3.py 1e7 4 > $R/gpurun_out/pmc_c3_$i.log 2>&1 || echo "pass $i failed: $(tail -2 $R/gpurun_out/pmc_c3_$i.log)"
 done
 python3 - $R/gpurun_out/pmc_c3_1 $R/gpurun_out/pmc_c3_2 $R/gpurun_out/pmc_c3_3 $R/gpurun_out/pmc_c3_4 <<'PY'
-import collections, csv, glob, sys
+import collections, csv, glob, re, sys
 agg = collections.defaultdict(list)
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/*/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "31u, true, 0>" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if re.search(r"berg_kernel<false, false, 31u, true, \d>", r["Kernel_Name"])]
         ids = sorted({int(r["Dispatch_Id"]) for r in rows})[1:]      # the first launch allocates scratch: leave it out
         for r in rows:
             if int(r["Dispatch_Id"]) in ids: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))

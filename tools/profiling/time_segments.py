@@ -18,10 +18,11 @@ lib.kid_exp_timing.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.kid_exp_timing(out, 1)
 ib.run(8); ib.sync()
 lib.kid_exp_timing(out, 0)
-names = ["prologue (loads, runs, packets)", "adjust_index (stages 2-4)", "lat terms", "interp_flds", "accel", "stage tail / sums", "after the loop + stores",
-         "second interp", "thermodynamics", "spreading + flush", "final stores"]
-tot = sum(out[1 + q] for q in range(11))
+names = ["prologue: rest (parking, accel_pre, first stage setup)", "adjust_index (stages 2-4)", "lat terms", "interp_flds", "accel", "stage tail / sums", "after the loop + stores",
+         "second interp", "thermodynamics", "spreading + flush", "final stores",
+         "prologue: issue loads, wait for alive / stamp / cell", "prologue: runs, packet loads issued", "prologue: wait for packets and fields"]
+tot = sum(out[1 + q] for q in range(14))
 print("waves %d (hot + general builds), cycles per wave %.0f" % (out[0], tot / max(out[0], 1)))
-for q, nm in enumerate(names):
+for q, nm in sorted(enumerate(names), key=lambda x: (x[0] + 3) % 14 if x[0] in (11, 12, 13) else x[0] + 3 if x[0] > 0 else 3.5):
     print("%-34s %5.1f %%" % (nm, 100.0 * out[1 + q] / tot))
 ib.close()

@@ -174,7 +174,8 @@ class PipelinedStepper:
             self.new_done[cur].record(self.comm)            # behind the general-build launches of this step
             with torch.cuda.stream(self.xchg):
                 self.xchg.wait_event(self.new_done[cur])
-                self.dist.all_reduce(self.views[cur][0])   # scalars + live planes: one collective
+                if self.dist is not None:
+                    self.dist.all_reduce(self.views[cur][0])   # scalars + live planes: one collective
                 ib.set_stream(self.xchg.cuda_stream)
                 ib.step_gather()
                 self.gather_done[cur].record(self.xchg)

@@ -61,6 +61,11 @@ template <int K> struct Fl {
 #ifndef KID_HOT_WG
 #define KID_HOT_WG 64
 #endif
+#ifdef KID_EXP_NO_PRIO
+#define KID_PRIO_ON false
+#else
+#define KID_PRIO_ON true
+#endif
 #ifndef KID_GENERAL_WAVES_PER_EU
 #define KID_GENERAL_WAVES_PER_EU 2   // <=256 registers: a general-build wave can share a SIMD with a hot-build wave (pipelined mode)
 #endif
@@ -75,8 +80,8 @@ struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;   
 #define KID_NUM_VGPR_ATTR
 #endif
 // The plain hot build of the fused RK4 step (BASELINE configs 1-2 and the headline line) runs THREE waves per SIMD: with the four
-// stages unrolled it needs 174 registers (the rolled loop 203: the stage-dependent selects and the loop-carried copies), six of
-// them spilled at the 168 a third wave allows; and its LDS fits twelve times into a CU (160 KB in 1280-byte blocks: 12800 bytes
+// stages unrolled it needs 160 registers (the rolled loop 203: the stage-dependent selects and the loop-carried copies; 168 is
+// what a third wave allows); and its LDS fits twelve times into a CU (160 KB in 1280-byte blocks: 12800 bytes
 // per wave) with KID_HOT3_SLOTS cell packets and KID_HOT3_CHUNK staging rows.  Measured at 1e7 bergs: 0.98 -> 0.88 ms per launch.
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg {
 #if defined(KID_EXACT_MATH) || defined(KID_EXP_NO_HOT3)
@@ -85,6 +90,9 @@ template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg 
   static constexpr bool three = FAST && RK && OLD_ORDER && K == 1 && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
 #endif
   static constexpr int slots = three ? 12 : KID_MAXRUN;   // cell packets per wave
+  // a slot per distinct cell, or per run: a sparse population (the footloose profile's 5 bergs per cell: 13 cells per wave, a run
+  // each) gains nothing from the search for repeated cells and pays ~2 % for it (measured, config 3)
+  static constexpr bool distinct = K != 2;
   static constexpr int chunk = three ? 10 : KID_CHUNK;    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
   static constexpr int waves = !FAST ? KID_GENERAL_WAVES_PER_EU : (three ? 3 : KID_WAVES_PER_EU);
 };
@@ -115,7 +123,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
   // The wave that is fetching issues first: its loads, the run table and the packet DMA are a few hundred instructions that would
   // otherwise take turns with the other wave's arithmetic, and every cycle they finish earlier is a cycle of memory latency that
   // overlaps with that arithmetic (measured at 1e7 bergs: 1.033 -> 1.016 ms per launch with the flush below)
-  if (FAST) __builtin_amdgcn_s_setprio(3);
+  if (FAST && KID_PRIO_ON) __builtin_amdgcn_s_setprio(3);
   const bool inrange = tid < total;
   const long long k = inrange ? (FAST ? redo.k0 + tid : (long long)redo.list[tid]) : 0ll;
   const long long kk = inrange ? k : (n - 1);
@@ -174,7 +182,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
     const int lane = (int)__lane_id();
     const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const int myrun = __popcll(seg.heads & le) - 1;
-    // One packet slot per DISTINCT cell of the wave's runs.  As the cell order decays between two re-binnings a wave collects
+    // One packet slot per DISTINCT cell of the wave's runs (Cfg::distinct).  As the cell order decays between two re-binnings a wave collects
     // out-of-place bergs, each a run of its own that also splits the run it sits in: a slot per run staged the same packet
     // again and again and ran out of slots two thirds into a 16-step interval (runs ~ 1.5 + 1.3 per step at 139 bergs per
     // cell), although the bergs of a tile only ever spread over the handful of cells around where they were binned.
@@ -183,6 +191,23 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
     // in flight before the single wait.  The cell of a slot is wave-uniform (a v_readlane): scalar address arithmetic.
     const gchar *gp = (const gchar *)g.pkt;
     static_assert(PK_SIZE * 8 == 34 * 16 && (PK_STRIDE * 8) % 16 == 0 && (PK_GSTRIDE * 8) % 16 == 0, "packet = 34 lanes x 16 bytes, 16-byte aligned slots");
+    int myslot;
+    if constexpr (!Cfg::distinct) {   // one slot per run
+    if (myrun >= SLOTS) {
+      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
+      was_alive = false;
+    }
+    const int nstage = seg.R < SLOTS ? seg.R : SLOTS;
+    const int mycell = seg.cell[lane < SLOTS ? lane : 0];
+    const unsigned loff = (unsigned)lane * 16u;
+    for (int u = 0; u < nstage; ++u) {  // wave-uniform
+      const int cu = __builtin_amdgcn_readlane(mycell, u);
+      if (cu >= 0 && lane < 34)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)cu * (size_t)(PK_GSTRIDE * 8) + loff),
+                                         (__attribute__((address_space(3))) void *)(wpk + u * PK_STRIDE), 16, 0, 0);
+    }
+    myslot = myrun < 0 ? 0 : myrun;
+    } else {
     const int rc = (lane < seg.R) ? seg.cell[lane] : -1;   // lane r < R: the cell of run r (-1: a run of dead lanes)
     const unsigned loff = (unsigned)lane * 16u;
     unsigned long long rem = __ballot(rc >= 0);
@@ -198,14 +223,15 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
       rem &= ~__ballot(mine);
       ++nslot;
     }
-    const int myslot = __shfl(slot_of_run, myrun < 0 ? 0 : myrun);
+    myslot = __shfl(slot_of_run, myrun < 0 ? 0 : myrun);
     // more distinct cells than slots: the lanes of the cells beyond go to the general build one by one (handing over the whole
     // wave made 15 % of the population take the slow path by the end of a 16-step interval)
     if (myslot >= SLOTS) {
       if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
       was_alive = false;
     }
-    __builtin_amdgcn_s_setprio(0);
+    }
+    if (KID_PRIO_ON) __builtin_amdgcn_s_setprio(0);
     KID_TICK(12);   // (runs found, packet loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -380,7 +406,7 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
                        (K == 0 && b.orient) ? b.orient[kk] : p.initial_orientation);
       if (!Fl<K>::no_diag(fl)) berg_diagnostics<K>(g, p, cellv, t, d.uvel, d.vvel, d.ine, d.jne, act2, acc, ncell, seg);
     }
-    if (FAST) __builtin_amdgcn_s_setprio(3);   // ... and the wave that is about to retire: its slot goes to a wave that starts fetching
+    if (FAST && KID_PRIO_ON) __builtin_amdgcn_s_setprio(3);   // ... and the wave that is about to retire: its slot goes to a wave that starts fetching
     seg_flush(seg, acc, ncell);
     KID_MARK("spread_done"); KID_TICK(9);
   }

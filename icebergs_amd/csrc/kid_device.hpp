@@ -900,8 +900,8 @@ struct BergDyn {
 // ---------------------------------------------------------------------------------------------------------
 // IB:7331-7679 Runge_Kutta_stepping.  env is only read when .not.old_interp_flds_order.
 //
-// The four stages run as ONE loop body (not unrolled): the whole kernel has to stay inside the 64 KB
-// instruction cache a CU pair shares, and four inlined copies of interp_flds + accel + the cell search do not.
+// The general build runs the four stages as ONE loop body; the hot build unrolls them (33 KB of code, inside the 64 KB
+// instruction cache a CU pair shares): with `s` a constant the stage selects and the loop-carried copies go, 203 -> 160 registers.
 // The reference's sums (u1+u4)+2(u2+u3) are kept bit-for-bit by carrying the two partial sums A=(x1[+x4]) and
 // B=(x2[+x3]) per quantity.  On the polar tangent plane (lat>89, IB:7393) the same loop advances the
 // tangent-plane position/velocity instead; its rot* helpers are out of line (cold).
@@ -988,6 +988,9 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
     {  // one running sum q1 + 2 q2 + 2 q3 + q4 per quantity (kept in A, B stays 0): half the registers of the (q1+q4), (q2+q3) pairs
       const double wq = (s == 0 || s == 3) ? 1. : 2.;
       Au = Au + wq * qu; Av = Av + wq * qv; Aax = Aax + wq * qax; Aay = Aay + wq * qay; Aaxn = Aaxn + wq * qaxn; Aayn = Aayn + wq * qayn;
+      // (unrolled stages: the sums are formed here and now -- left to itself the scheduler sinks the four additions of every
+      // quantity to the end of the step and keeps, or spills, the terms until then)
+      if constexpr (FAST) asm volatile("" : "+v"(Au), "+v"(Av), "+v"(Aax), "+v"(Aay));
     }
 #endif
     if (s < 3) {  // X_{k+1} = X1 + c V_k ; V_{k+1} = V1 + c A_k   (c = dt/2, dt/2, dt)

@@ -17,7 +17,7 @@ tot = collections.Counter()
 for s, o in ops.items(): tot.update(o)
 def cls(k):
     if not k.startswith("v_"): return "salu" if k.startswith("s_") else ("lds" if k.startswith("ds_") else "vmem/other")
-    if k in ("v_fma_f64", "v_mul_f64", "v_add_f64"): return "valu fp64 add/mul/fma"
+    if k.startswith(("v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64")): return "valu fp64 add/mul/fma"
     if k.startswith(("v_rcp", "v_rsq", "v_sqrt", "v_log", "v_exp", "v_sin", "v_cos")): return "valu transcendental"
     if k.startswith("v_cmp") or k.startswith("v_cmpx"): return "valu compare"
     if k.startswith("v_cndmask"): return "valu select (v_cndmask_b32)"

@@ -69,15 +69,56 @@ __device__ __noinline__ void fl_displacement(const DevGrid &g, const kid_params 
   fl_disp_x = fx; fl_disp_y = fy;
 }
 
-// calve_fl_icebergs IB:6405-6569; `draw` picks the random number of this event; returns false if the SoA is full
+// calve_fl_icebergs IB:6405-6569 in two halves.
+// (1) fl_calve_event, at the moment of the event, inline in the rare branch of whoever runs footloose_core: reserves the child's
+//     row and writes what depends on the parent's state at this very moment -- the child's size, masses and provisional id, the
+//     parent's share of the footloose bits for a berg made from bits -- and leaves the parent's length and width (which the
+//     thermodynamics of the same launch will change) in the child's start_lon / start_lat for the second half.
+// (2) fl_place_children_kernel, one lane per child once the pass has ended and the host knows how many there are: position
+//     (the random number of the event, get_footloose_displacement, find_cell and its fall-backs, pos_within_cell), the members
+//     copied from the parent -- none of which the thermodynamics touches -- and the constants.
+// As ONE out-of-line function in the middle of the fused step this cost the hot build of the footloose profile 100 registers:
+// everything live across a call has to sit in callee-saved registers, which are half of the file (252 registers + 240 bytes of
+// scratch per lane with the call, 155 without it).  Returns false if the SoA is full.
+constexpr int KID_FL_STASH_LEN = KID_B_START_LON, KID_FL_STASH_WID = KID_B_START_LAT;
 template <class BP>
-__device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long pk,
-                                         double k, double l_b, bool from_bits, unsigned draw) {
+__device__ __forceinline__ bool fl_calve_event(const kid_params &p, const BP &b, const FlChildCtx &cx, long long pk, double k, double l_b, bool from_bits) {
   const int slot = atomicAdd(cx.cursor, 1);
   const long long c = cx.n + slot;
   if (c >= cx.capacity) return false;
+  b.f[KID_FL_STASH_LEN][c] = b.f[KID_B_LENGTH][pk]; b.f[KID_FL_STASH_WID][c] = b.f[KID_B_WIDTH][pk];
+  const double pms = b.f[KID_B_MASS_SCALING][pk];
+  if (from_bits) {  // IB:6488-6497
+    double Lfl, Wfl, Tfl;
+    fl_bits_dimensions_inl<0>(p, b.f[KID_B_THICKNESS][pk], Lfl, Wfl, Tfl);
+    const double cmass = Tfl * Lfl * Wfl * p.rho_bergs;
+    const double cms = k * p.new_berg_from_fl_bits_mass_thres / cmass;
+    b.f[KID_B_LENGTH][c] = Lfl; b.f[KID_B_WIDTH][c] = Wfl; b.f[KID_B_THICKNESS][c] = Tfl;
+    b.f[KID_B_MASS][c] = cmass; b.f[KID_B_MASS_SCALING][c] = cms;
+    const double percent_fl = (cmass * cms) / (b.f[KID_B_MASS_OF_FL_BITS][pk] * pms);
+    b.f[KID_B_MASS_OF_BITS][c] = (percent_fl * b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk] * pms) / cms;
+    b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk] = (1 - percent_fl) * b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk];
+    b.f[KID_B_MASS_OF_FL_BITS][pk] = b.f[KID_B_MASS_OF_FL_BITS][pk] - k * p.new_berg_from_fl_bits_mass_thres / pms;
+  } else {          // IB:6499-6504
+    const double len = l_b * 3., wid = l_b, thick = b.f[KID_B_THICKNESS][pk];
+    b.f[KID_B_LENGTH][c] = len; b.f[KID_B_WIDTH][c] = wid; b.f[KID_B_THICKNESS][c] = thick;
+    b.f[KID_B_MASS][c] = wid * len * thick * p.rho_bergs;
+    b.f[KID_B_MASS_SCALING][c] = pms * k;
+    b.f[KID_B_MASS_OF_BITS][c] = 0.0;
+  }
+  // provisional id: -(1 + 2 * parent row + event); fl_assign_ids_* replaces it by generate_id's value (FW:4165-4179)
+  b.id[c] = -(((int64_t)pk << 1 | (from_bits ? 1 : 0)) + 1);
+  return true;
+}
+template <class BP>
+__device__ __forceinline__ void fl_place_child(const DevGrid &g, const kid_params &p, const BP &b, unsigned step, long long c) {
+  const int64_t prov = -b.id[c] - 1;
+  const long long pk = (long long)(prov >> 1);
+  const unsigned draw = (unsigned)(prov & 1);   // 0 for the calving block (IB:2631), 1 for the new-berg-from-bits block (IB:2664)
+  const double plen = b.f[KID_FL_STASH_LEN][c], pwid = b.f[KID_FL_STASH_WID][c];
 #pragma unroll 1
-  for (int f = 0; f < KID_NB_F64; ++f) b.f[f][c] = 0.0;
+  for (int f = 0; f < KID_NB_F64; ++f)
+    if (f != KID_B_LENGTH && f != KID_B_WIDTH && f != KID_B_THICKNESS && f != KID_B_MASS && f != KID_B_MASS_SCALING && f != KID_B_MASS_OF_BITS) b.f[f][c] = 0.0;
   const int pi = b.i[KID_BI_INE][pk], pj = b.i[KID_BI_JNE][pk];
   const double plon = b.f[KID_B_LON][pk], plat = b.f[KID_B_LAT][pk];
   double fl_disp_x = 0.0, fl_disp_y = 0.0;
@@ -85,8 +126,7 @@ __device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, 
   if (displace) {
     // IB:2631 / 2664: a fresh number per event, or the one number of the run (fl_init_child_xy_by_pe)
     const double rn = p.fl_init_child_xy_by_pe ? kid_fl_uniform((uint32_t)p.fl_rng_seed, 0, 0u, 0u)
-                                               : kid_fl_uniform((uint32_t)p.fl_rng_seed, b.id[pk], cx.step, draw);
-    const double plen = b.f[KID_B_LENGTH][pk], pwid = b.f[KID_B_WIDTH][pk];
+                                               : kid_fl_uniform((uint32_t)p.fl_rng_seed, b.id[pk], step, draw);
     fl_displacement(g, p, rn, plon, plat, plen, pwid, fl_disp_x, fl_disp_y);
     double clon = plon + fl_disp_x, clat = plat + fl_disp_y;   // IB:6433-6435
     int ci, cj;
@@ -114,33 +154,12 @@ __device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, 
     b.f[KID_B_XI][c] = b.f[KID_B_XI][pk]; b.f[KID_B_YJ][c] = b.f[KID_B_YJ][pk];
     b.i[KID_BI_INE][c] = pi; b.i[KID_BI_JNE][c] = pj;
   }
-  const double pms = b.f[KID_B_MASS_SCALING][pk];
-  if (from_bits) {  // IB:6488-6497
-    double Lfl, Wfl, Tfl;
-    fl_bits_dimensions(p, b.f[KID_B_THICKNESS][pk], Lfl, Wfl, Tfl);
-    const double cmass = Tfl * Lfl * Wfl * p.rho_bergs;
-    const double cms = k * p.new_berg_from_fl_bits_mass_thres / cmass;
-    b.f[KID_B_LENGTH][c] = Lfl; b.f[KID_B_WIDTH][c] = Wfl; b.f[KID_B_THICKNESS][c] = Tfl;
-    b.f[KID_B_MASS][c] = cmass; b.f[KID_B_MASS_SCALING][c] = cms;
-    const double percent_fl = (cmass * cms) / (b.f[KID_B_MASS_OF_FL_BITS][pk] * pms);
-    b.f[KID_B_MASS_OF_BITS][c] = (percent_fl * b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk] * pms) / cms;
-    b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk] = (1 - percent_fl) * b.f[KID_B_MASS_OF_FL_BERGY_BITS][pk];
-    b.f[KID_B_MASS_OF_FL_BITS][pk] = b.f[KID_B_MASS_OF_FL_BITS][pk] - k * p.new_berg_from_fl_bits_mass_thres / pms;
-  } else {          // IB:6499-6504
-    const double len = l_b * 3., wid = l_b, thick = b.f[KID_B_THICKNESS][pk];
-    b.f[KID_B_LENGTH][c] = len; b.f[KID_B_WIDTH][c] = wid; b.f[KID_B_THICKNESS][c] = thick;
-    b.f[KID_B_MASS][c] = wid * len * thick * p.rho_bergs;
-    b.f[KID_B_MASS_SCALING][c] = pms * k;
-    b.f[KID_B_MASS_OF_BITS][c] = 0.0;
-  }
   b.f[KID_B_START_LON][c] = b.f[KID_B_LON][c]; b.f[KID_B_START_LAT][c] = b.f[KID_B_LAT][c];
   b.f[KID_B_LON_OLD][c] = b.f[KID_B_LON_OLD][pk] + fl_disp_x; b.f[KID_B_LAT_OLD][c] = b.f[KID_B_LAT_OLD][pk] + fl_disp_y;
   b.f[KID_B_START_DAY][c] = p.current_yearday;
   b.f[KID_B_MASS_OF_FL_BITS][c] = 0.0; b.f[KID_B_MASS_OF_FL_BERGY_BITS][c] = 0.0;
   b.f[KID_B_FL_K][c] = -1.0;
   b.i[KID_BI_START_YEAR][c] = p.current_year;
-  // provisional id: -(1 + 2 * parent row + event); fl_assign_ids_* replaces it by generate_id's value (FW:4165-4179)
-  b.id[c] = -(((int64_t)pk << 1 | (from_bits ? 1 : 0)) + 1);
   b.f[KID_B_HALO_BERG][c] = 0.0;
   const int same[] = {KID_B_START_MASS, KID_B_UVEL, KID_B_VVEL, KID_B_AXN, KID_B_AYN, KID_B_BXN, KID_B_BYN,
                       KID_B_UVEL_PREV, KID_B_VVEL_PREV, KID_B_UVEL_OLD, KID_B_VVEL_OLD, KID_B_HEAT_DENSITY,
@@ -150,13 +169,17 @@ __device__ __noinline__ bool calve_child(const DevGrid &g, const kid_params &p, 
   for (unsigned q = 0; q < sizeof(same) / sizeof(same[0]); ++q) b.f[same[q]][c] = b.f[same[q]][pk];
   b.i[KID_BI_N_BONDS][c] = 0;
   b.i[KID_BI_ALIVE][c] = 1;
-  return true;
+}
+template <class BP>
+__global__ void __launch_bounds__(64) fl_place_children_kernel(const DevGrid g, const kid_params *__restrict__ pp, const BP *__restrict__ bt, long long n_old, int m, unsigned step) {
+  const int q = (int)(blockIdx.x * 64u + threadIdx.x);
+  if (q < m) fl_place_child(g, *pp, *bt, step, n_old + q);
 }
 
 // footloose_calving for one berg (IB:2503-2734).  The berg's own values come in and go out through the arguments (the fused
 // step holds them in registers: no round trip through memory between its evolve and its thermodynamics); whatever
-// changes is ALSO written to the berg's row where the reference changes it, because calve_child reads the parent's row.
-// bits_rows_touched: calve_child(from_bits) has rewritten mass_of_fl_bits and mass_of_fl_bergy_bits of the row.
+// changes is ALSO written to the berg's row where the reference changes it, because fl_calve_event reads the parent's row.
+// bits_rows_touched: fl_calve_event(from_bits) has rewritten mass_of_fl_bits and mass_of_fl_bergy_bits of the row.
 template <class BP>
 __device__ __forceinline__ void footloose_core(const DevGrid &g, const kid_params &p, const BP &b, const FlChildCtx &cx, long long q, int i, int j, double area,
                                                double ms, double static_berg, double &M, double &T, double &W, double &L, double &flk, double &bits,
@@ -195,7 +218,7 @@ __device__ __forceinline__ void footloose_core(const DevGrid &g, const kid_param
       }
       const double dA = L * W - Ln * Wn;
       if (p.fl_style == KID_FL_STYLE_NEW_BERGS) {
-        if (!calve_child(g, p, b, cx, q, k, l_b, false, 0u)) nerr += 1.;
+        if (!fl_calve_event(p, b, cx, q, k, l_b, false)) nerr += 1.;
         ncalved += 1.;
       } else {
         const double dM_fl_bits = p.rho_bergs * T * dA;
@@ -214,7 +237,7 @@ __device__ __forceinline__ void footloose_core(const DevGrid &g, const kid_param
   }
   if (bits * ms > p.new_berg_from_fl_bits_mass_thres) {  // IB:2663-2673
     const double k = floor(bits * ms / p.new_berg_from_fl_bits_mass_thres);
-    if (!calve_child(g, p, b, cx, q, k, l_b, true, 1u)) nerr += 1.;
+    if (!fl_calve_event(p, b, cx, q, k, l_b, true)) nerr += 1.;
     bits_rows_touched = true;
     ncalved += 1.;
     if (area != 0.) unsafeAtomicAdd(acc + (size_t)KID_A_FL_BITS_SRC * ncell + c, -(k * p.new_berg_from_fl_bits_mass_thres / (p.dt * area)));

@@ -1440,6 +1440,13 @@ static int refresh_tables(kid_handle *h) {
 }
 // ids of the children a footloose pass appended to rows [n_old, n_old + m): the per-cell counter values in the order the
 // reference's loop would have met the events (kid_footloose.hpp, fl_assign_ids_*)
+// second half of calve_fl_icebergs for the children of one pass (kid_footloose.hpp): positions, copied members, constants
+static int fl_place_children(kid_handle *h, long long n_old, int m, unsigned step) {
+  if (m <= 0) return KID_OK;
+  hipLaunchKernelGGL(fl_place_children_kernel<BergPtrs>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, h->stream, dev_grid(h), (const kid_params *)h->d_params, (const BergPtrs *)h->d_bp, n_old, m, step);
+  KID_HIP(h, hipGetLastError());
+  return KID_OK;
+}
 static int fl_assign_ids(kid_handle *h, long long n_old, int m) {
   if (m <= 0) return KID_OK;
   if (!h->d_fl_head) {
@@ -1470,6 +1477,7 @@ int kid_footloose_calving(kid_handle *h) {
   if (rc) return rc;
   h->flags.has_fl = 1;
   KID_HIP(h, hipMemsetAsync(h->d_fl_cursor, 0, sizeof(int), h->stream));
+  const unsigned fl_step_now = h->fl_step;
   FlChildCtx cx{h->d_fl_cursor, h->d_iceberg_counter, (long long)h->n, (long long)h->capacity, h->gd.iec - h->gd.isc + 1, h->fl_step++};
   hipLaunchKernelGGL(footloose_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, dev_grid(h), h->d_params, h->d_bp, cx, h->d_acc, h->ncell);
   KID_HIP(h, hipGetLastError());
@@ -1482,6 +1490,8 @@ int kid_footloose_calving(kid_handle *h) {
     h->err = "footloose calving ran out of capacity: create the handle with room for child bergs";
     return KID_ECAPACITY;
   }
+  rc = fl_place_children(h, h->n, appended, fl_step_now);
+  if (rc) return rc;
   rc = fl_assign_ids(h, h->n, appended);
   h->n += appended;
   return rc;
@@ -1571,6 +1581,7 @@ int kid_step_local(kid_handle *h) {
     KID_HIP(h, hipMemsetAsync(h->d_fl_cursor, 0, sizeof(int), h->stream));
     const long long n_old = h->n;
     rc = p.old_interp_flds_order ? launch_berg<PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD>(h) : launch_berg<PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD>(h);
+    const unsigned fl_step_now = h->fl_step;
     h->fl_step += 1u;   // one footloose pass (hot and general build of this launch share the step word)
     if (rc) return rc;
     int appended = 0;  // the population grew: the host needs the new size before the next launch
@@ -1582,6 +1593,8 @@ int kid_step_local(kid_handle *h) {
       return KID_ECAPACITY;
     }
     h->n = n_old + appended;
+    rc = fl_place_children(h, n_old, appended, fl_step_now);
+    if (rc) return rc;
     rc = fl_assign_ids(h, n_old, appended);
     if (rc) return rc;
     return p.old_interp_flds_order ? launch_berg<PH_THERMO | PH_SPREAD>(h, n_old, appended) : launch_berg<PH_INTERP | PH_THERMO | PH_SPREAD>(h, n_old, appended);

@@ -180,7 +180,9 @@ def main():
     ap.add_argument("--resort", type=int, default=12, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 rehearsal without N GPUs: every rank uses GPU 0 and the exchange goes through gloo (what is exercised is the N>1 code path, not its speed)")
     ap.add_argument("--advance-clock", action="store_true", help="kid_set_params with an advancing current_yearday before every step, as a model run does")
-    ap.add_argument("--no-slow-lane", action="store_true", help="keep the general build between two hot builds (the plain schedule)")
+    ap.add_argument("--slow-lane", action="store_true", help="step the bergs the hot build hands over on a second stream for two steps (round 2's default: it paid while the "
+                    "hot build left room for other kernels on a SIMD; with three waves of 160 registers it does not: 1.09 against 1.05 ms/step at 1e7 bergs)")
+    ap.add_argument("--no-slow-lane", action="store_true", help="(default since round 3) keep the general build between two hot builds")
     ap.add_argument("--no-other-configs", action="store_true", help="headline only: skip the informational runs after the timed region (store-on figure, configs 3 and 4)")
     ap.add_argument("--cpu-bergs", type=int, default=500_000)
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -235,7 +237,7 @@ def main():
     from icebergs_amd.distributed import ShardedStepper, PipelinedStepper, accumulator_views
     _, count = ib.accum_device_ptr()
     multi = world > 1 or args.force_collective
-    slow_lane = not args.no_slow_lane and not args.split_general and not args.no_pipeline
+    slow_lane = args.slow_lane and not args.no_slow_lane and not args.split_general and not args.no_pipeline
     pipelined = (multi and not args.no_pipeline) or args.split_general or slow_lane
     if pipelined:
         # the all-reduce (N>1) and the gather of step k run on a second stream under the per-berg kernels of step k+1;

@@ -19,6 +19,6 @@ cd $R
 python bench.py > gpurun_out/bench_round.log 2>&1; tail -1 gpurun_out/bench_round.log | cut -c1-400
 cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_round
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_round -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $R/gpurun_out/prof_round.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_round -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs > $R/gpurun_out/prof_round.log 2>&1
 cp $R/gpurun_out/prof_round/*/*kernel_stats.csv $R/gpurun_out/round_kernel_stats.csv
 head -c 600 $R/gpurun_out/round_kernel_stats.csv

@@ -81,19 +81,25 @@ struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;   
 #endif
 // The plain hot build of the fused RK4 step (BASELINE configs 1-2 and the headline line) runs THREE waves per SIMD: with the four
 // stages unrolled it needs 160 registers (the rolled loop 203: the stage-dependent selects and the loop-carried copies; 168 is
-// what a third wave allows); and its LDS fits twelve times into a CU (160 KB in 1280-byte blocks: 12800 bytes
-// per wave) with KID_HOT3_SLOTS cell packets and KID_HOT3_CHUNK staging rows.  Measured at 1e7 bergs: 0.98 -> 0.88 ms per launch.
+// what a third wave allows); and its LDS fits twelve times into a CU (160 KB in 1280-byte blocks: 12800 bytes per wave) with
+// KID_HOT3_SLOTS cell packets and KID_HOT3_CHUNK staging rows.  Measured at 1e7 bergs: 0.98 -> 0.88 ms per launch with 12 + 10;
+// 11 + 11 holds the step's eleven staged values (floating_melt, berg_melt, nine mass_on_ocean slots; the heat-flux plane is
+// staged only by a wave that has heat) in ONE flush instead of two: 0.805 -> 0.777 ms.
+#ifndef KID_HOT3_SLOTS
+#define KID_HOT3_SLOTS 11
+#define KID_HOT3_CHUNK 11
+#endif
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg {
 #if defined(KID_EXACT_MATH) || defined(KID_EXP_NO_HOT3)
   static constexpr bool three = false;
 #else
   static constexpr bool three = FAST && RK && OLD_ORDER && K == 1 && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
 #endif
-  static constexpr int slots = three ? 12 : KID_MAXRUN;   // cell packets per wave
+  static constexpr int slots = three ? KID_HOT3_SLOTS : KID_MAXRUN;   // cell packets per wave
   // a slot per distinct cell, or per run: a sparse population (the footloose profile's 5 bergs per cell: 13 cells per wave, a run
   // each) gains nothing from the search for repeated cells and pays ~2 % for it (measured, config 3)
   static constexpr bool distinct = K != 2;
-  static constexpr int chunk = three ? 10 : KID_CHUNK;    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
+  static constexpr int chunk = three ? KID_HOT3_CHUNK : KID_CHUNK;    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
   static constexpr int waves = !FAST ? KID_GENERAL_WAVES_PER_EU : (three ? 3 : KID_WAVES_PER_EU);
 };
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K = 0>

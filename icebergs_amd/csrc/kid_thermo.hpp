@@ -348,10 +348,10 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
     for (int q = 0; q < 10; ++q) KID_ACC(KID_A_MELT_BY_CLASS + q, (kc == q) ? melt * rarea * ms : 0.);
   }
   melt = melt * b.heat_density;
-  KID_ACC(KID_A_CALVING_HFLX, melt * rarea * ms);
   {
     const double hv = ok ? melt * ms * dt : 0.;
-    if (__ballot(hv != 0.) != 0ull) {   // heat_density = 0 everywhere (every BASELINE config): nothing to sum
+    if (__ballot(hv != 0.) != 0ull) {   // heat_density = 0 everywhere (every BASELINE config): nothing to sum, nothing to stage
+      KID_ACC(KID_A_CALVING_HFLX, melt * rarea * ms);
       const double h = wave_sum(hv);
       if (__lane_id() == 0 && h != 0.) unsafeAtomicAdd(scal + KID_S_NET_HEAT_TO_OCEAN, h);
     }

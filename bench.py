@@ -352,7 +352,8 @@ def main():
         }
         # The headline runs the way config 2 is configured (ignore_traj=T: berg%uo..hi are not stored back, IB:2890-2894 has no
         # reader).  A host that samples trajectories, prints bergs_chksum or migrates bergs needs those 11 members: the same
-        # population with the store on (the K=0 build: namelist switches read at run time) -- informational, not `value`.
+        # population with the store on (the plain hot build again, K = 3: the eleven members written right after the
+        # thermodynamics' interpolation) -- informational, not `value`.
         line["roofline"]["store_environment"] = False
         if world == 1 and not args.force_collective and not args.no_other_configs:
             ib.set_store_environment(True)
@@ -375,7 +376,7 @@ def main():
                 "ms_per_step": 1e3 * el1 / nst, "value": args.bergs * nst / el1, "kernel_ms_avg": k_ms, "steps": nst,
                 "algorithmic_bytes_per_berg_step": ALGO_BYTES_PER_BERG_STEP + 11 * 8,
                 "frac": ((ALGO_BYTES_PER_BERG_STEP + 11 * 8) * per_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
-                "note": "berg%uo,vo,ui,vi,ua,va,ssh_x,ssh_y,sst,cn,hi stored every step (IB:2890-2894): +88 B per berg-step, the run-time-namelist build of the kernel"}
+                "note": "berg%uo,vo,ui,vi,ua,va,ssh_x,ssh_y,sst,cn,hi stored every step (IB:2890-2894): +88 B per berg-step; berg_kernel<true, true, 14u, true, 3>, the plain hot build that stores them"}
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         if world == 1 and not args.no_other_configs and not args.force_collective:

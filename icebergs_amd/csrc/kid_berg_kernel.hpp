@@ -36,11 +36,11 @@ __device__ __forceinline__ void keep(double x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void keep(int32_t x) { asm volatile("" ::"v"(x)); }
 __device__ __forceinline__ void stg(double *q, long long k, double v) { *(gdouble *)((gchar *)q + (size_t)((unsigned)k << 3)) = v; }
 __device__ __forceinline__ void stg(int32_t *q, long long k, int32_t v) { *(gint32 *)((gchar *)q + (size_t)((unsigned)k << 2)) = v; }
-// the plain build (K = 1, kid_device.hpp) is launched only with all five flags zero; the footloose profile (K = 2) with no static
+// the plain builds (K = 1 and, with store_env on, K = 3; kid_device.hpp) are launched only with the other four flags zero; the footloose profile (K = 2) with no static
 // bergs, footloose state present, no footprint planes and the diagnostics call on (store_env as the handle says)
 template <int K> struct Fl {
-#define KID_X(name, k2) static __device__ __forceinline__ int name(const Flags &f) { if constexpr (K == 1) return 0; else if constexpr (K == 2) return k2; else return f.name; }
-  KID_X(has_static, 0) KID_X(has_fl, 1) KID_X(store_env, f.store_env) KID_X(footprint, 0) KID_X(no_diag, 0)
+#define KID_X(name, k1, k2, k3) static __device__ __forceinline__ int name(const Flags &f) { if constexpr (K == 1) return k1; else if constexpr (K == 2) return k2; else if constexpr (K == 3) return k3; else return f.name; }
+  KID_X(has_static, 0, 0, 0) KID_X(has_fl, 0, 1, 0) KID_X(store_env, 0, f.store_env, 1) KID_X(footprint, 0, 0, 0) KID_X(no_diag, 0, 0, 0)
 #undef KID_X
 };
 
@@ -93,7 +93,7 @@ template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg 
 #if defined(KID_EXACT_MATH) || defined(KID_EXP_NO_HOT3)
   static constexpr bool three = false;
 #else
-  static constexpr bool three = FAST && RK && OLD_ORDER && K == 1 && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
+  static constexpr bool three = FAST && RK && OLD_ORDER && (K == 1 || K == 3) && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
 #endif
   static constexpr int slots = three ? KID_HOT3_SLOTS : KID_MAXRUN;   // cell packets per wave
   // a slot per distinct cell, or per run: a sparse population (the footloose profile's 5 bergs per cell: 13 cells per wave, a run
@@ -382,6 +382,15 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
         const double od_keep = e.od;
         if (active) { interp_flds<K, HOTCHECKED>(p, cellv, d.xi, d.yj, e); env_dirty = true; }
         if (PH & PH_INTERP) e.od = od_keep;
+      }
+      // the environment the berg carries from here on is final (the thermodynamics only reads it): stored now, not at the end
+      // of the kernel -- thirteen values less to hold across the thermodynamics and the spreading
+      if (env_dirty && Fl<K>::store_env(fl) && was_alive && !skipped) {
+        stg(b.f[KID_B_UO], kk, e.uo); stg(b.f[KID_B_VO], kk, e.vo); stg(b.f[KID_B_UI], kk, e.ui); stg(b.f[KID_B_VI], kk, e.vi);
+        stg(b.f[KID_B_UA], kk, e.ua); stg(b.f[KID_B_VA], kk, e.va); stg(b.f[KID_B_SSH_X], kk, e.ssh_x); stg(b.f[KID_B_SSH_Y], kk, e.ssh_y);
+        stg(b.f[KID_B_SST], kk, e.sst); stg(b.f[KID_B_SSS], kk, e.sss); stg(b.f[KID_B_CN], kk, e.cn); stg(b.f[KID_B_HI], kk, e.hi);
+        if (PH & PH_INTERP) stg(b.f[KID_B_OD], kk, e.od);
+        env_dirty = false;
       }
       KID_PHASE_FENCE();
       KID_MARK("thermo_interp_done"); KID_TICK(7);

@@ -64,6 +64,8 @@ __device__ __forceinline__ void kid_tick(int idx, int idx2 = 0) {   // idx < 0: 
 // the hot build of that namelist carries none of the other branches (code size, scalar registers).  The host picks
 // K = 1 only when every one of these switches has exactly this value (plain_namelist() in kid_hip.hip).
 // ---------------------------------------------------------------------------------------------------------
+// K = 3: the plain namelist again, for a handle that stores the bergs' environment (kid_set_store_environment on: the members
+// berg%uo .. hi are written every step, IB:2890-2894) -- the same folded switches; K = 1 is the build that does not store it.
 // K = 2: the footloose profile (tests/footloose_tests/input.nml, BASELINE config 3: Verlet on a regular Cartesian grid, footloose
 // calving with bergy bits, the corrected rolling scheme, new spreading switched off by passive mode) folded the same way.
 // X(switch, value in the plain namelist, value in the footloose profile)
@@ -76,7 +78,7 @@ __device__ __forceinline__ void kid_tick(int idx, int idx2 = 0) {   // idx < 0: 
   X(Iceberg_melt_without_decay, 0, 0) X(grounding_fraction, 0., 0.) X(clipping_depth, 0., 0.) X(use_old_spreading, 1, 0)      \
   X(add_weight_to_ocean, 1, 0) X(time_average_weight, 0, 0) X(find_melt_using_spread_mass, 0, 0) X(mts, 0, 0) X(dem, 0, 0)
 template <int K> struct Sw {
-#define KID_X(name, plain, flp) static __device__ __forceinline__ auto name(const kid_params &p) -> decltype(p.name) { if constexpr (K == 1) return (decltype(p.name))(plain); else if constexpr (K == 2) return (decltype(p.name))(flp); else return p.name; }
+#define KID_X(name, plain, flp) static __device__ __forceinline__ auto name(const kid_params &p) -> decltype(p.name) { if constexpr (K == 1 || K == 3) return (decltype(p.name))(plain); else if constexpr (K == 2) return (decltype(p.name))(flp); else return p.name; }
   KID_SWITCHES(KID_X)
 #undef KID_X
 };
@@ -204,7 +206,7 @@ struct DevGrid {
 };
 
 // the plain build (K = 1) is for lat-lon grids (grid_is_latlon is the namelist default), the footloose profile (K = 2) for Cartesian ones
-template <int K> __device__ __forceinline__ bool grid_latlon(const DevGrid &g) { if constexpr (K == 1) return true; else if constexpr (K == 2) return false; else return g.latlon != 0; }
+template <int K> __device__ __forceinline__ bool grid_latlon(const DevGrid &g) { if constexpr (K == 1 || K == 3) return true; else if constexpr (K == 2) return false; else return g.latlon != 0; }
 
 struct Env { double uo, vo, ui, vi, ua, va, ssh_x, ssh_y, sst, sss, cn, hi, od; };
 

@@ -1237,7 +1237,7 @@ static bool plain_namelist(const kid_handle *h) {
   KID_SWITCHES(KID_X)
 #undef KID_X
   const Flags &f = h->flags;
-  return same && h->gd.grid_is_latlon && !p.pass_fields_to_ocean_model && !f.has_static && !f.has_fl && !f.store_env && !f.footprint && !f.no_diag &&
+  return same && h->gd.grid_is_latlon && !p.pass_fields_to_ocean_model && !f.has_static && !f.has_fl && !f.footprint && !f.no_diag &&
          !h->dbg.no_plain_build;
 }
 // ... and K = 2 with the footloose profile's (Cartesian grid, footloose state, no static bergs, no footprint planes)
@@ -1291,8 +1291,10 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
     }
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
-    if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                       \
+    if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain && !h->flags.store_env)                                \
       hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    else if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                  \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 3 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     else if (PH == (PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD) && !RKV && !OLDV && flprof)                           \
       hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD) && !RKV && !OLDV) ? 2 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     else                                                                                                                        \
@@ -1363,8 +1365,10 @@ static int launch_berg_lanes(kid_handle *h) {
     /* recorded even without a carry-over launch: everything enqueued on the side stream so far (the gather of the step  \
        before last included) is complete once the next prepass has waited for it */                                          \
     (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
-    if (RKV && OLDV && plain)                                                                                                   \
+    if (RKV && OLDV && plain && !h->flags.store_env)                                                                            \
       hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    else if (RKV && OLDV && plain)                                                                                              \
+      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 3 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     else                                                                                                                        \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(evF, M);                                                                                               \

@@ -599,7 +599,7 @@ __device__ __forceinline__ void spread_mass(const DevGrid &g, const kid_params &
   for (int s = 0; s < 9; ++s) {
     // slot unused by the whole wave: skipped (the plain build stages all nine, so that the number of staged values -- and
     // with it the one place where the staging block is flushed -- is known at compile time)
-    if (K != 1 && __ballot(ok && w[s] != 0.) == 0ull) continue;
+    if (K != 1 && K != 3 && __ballot(ok && w[s] != 0.) == 0ull) continue;
     cell_add(acc, ncell, base[0] + s, c, w[s] * vars[0] * Ifu, seg, ok);
     if (footprint) {  // wave-uniform: area / Uvel / Vvel footprints only when something downstream reads them
 #pragma unroll

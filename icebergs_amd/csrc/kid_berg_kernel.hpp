@@ -181,13 +181,15 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
   double *scal = acc - KID_NSCALAR;   // the step's scalar increments sit in front of plane 0 (kid_accum_device_ptr)
 
   // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
-  Seg seg = make_runs(was_alive ? g.idx(d.ine, d.jne) : -1, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
+  // (hot builds that give a packet slot to every distinct cell find the cells from the lanes' own keys and build the run tables
+  // after the packet loads are on their way; the others need the runs first)
+  const int mykey = was_alive ? g.idx(d.ine, d.jne) : -1;
+  Seg seg;
+  if constexpr (!(FAST && Cfg::distinct)) seg = make_runs(mykey, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
   const lds_double *pk = nullptr;
   if (FAST) {
     lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (SLOTS * PK_STRIDE);
     const int lane = (int)__lane_id();
-    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const int myrun = __popcll(seg.heads & le) - 1;
     // One packet slot per DISTINCT cell of the wave's runs (Cfg::distinct).  As the cell order decays between two re-binnings a wave collects
     // out-of-place bergs, each a run of its own that also splits the run it sits in: a slot per run staged the same packet
     // again and again and ran out of slots two thirds into a 16-step interval (runs ~ 1.5 + 1.3 per step at 139 bergs per
@@ -199,6 +201,8 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
     static_assert(PK_SIZE * 8 == 34 * 16 && (PK_STRIDE * 8) % 16 == 0 && (PK_GSTRIDE * 8) % 16 == 0, "packet = 34 lanes x 16 bytes, 16-byte aligned slots");
     int myslot;
     if constexpr (!Cfg::distinct) {   // one slot per run
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int myrun = __popcll(seg.heads & le) - 1;
     if (myrun >= SLOTS) {
       if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
       was_alive = false;
@@ -214,22 +218,24 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
     }
     myslot = myrun < 0 ? 0 : myrun;
     } else {
-    const int rc = (lane < seg.R) ? seg.cell[lane] : -1;   // lane r < R: the cell of run r (-1: a run of dead lanes)
+    // every lane knows its own cell: the wave walks over the distinct cells of its live lanes (first lane not yet served, its
+    // cell by v_readlane, a ballot of the lanes that share it) -- no table look-up, no shuffle
     const unsigned loff = (unsigned)lane * 16u;
-    unsigned long long rem = __ballot(rc >= 0);
-    int slot_of_run = 0, nslot = 0;
+    unsigned long long rem = __ballot(mykey >= 0);
+    int nslot = 0;
+    myslot = 0;
     while (rem != 0ull) {  // wave-uniform: one turn per distinct cell
       const int u = (int)__ffsll((long long)rem) - 1;
-      const int cu = __builtin_amdgcn_readlane(rc, u);
-      const bool mine = rc == cu;
-      if (mine) slot_of_run = nslot;
+      const int cu = __builtin_amdgcn_readlane(mykey, u);
+      const bool mine = mykey == cu;
+      if (mine) myslot = nslot;
       if (nslot < SLOTS && lane < 34)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)cu * (size_t)(PK_GSTRIDE * 8) + loff),
                                          (__attribute__((address_space(3))) void *)(wpk + nslot * PK_STRIDE), 16, 0, 0);
       rem &= ~__ballot(mine);
       ++nslot;
     }
-    myslot = __shfl(slot_of_run, myrun < 0 ? 0 : myrun);
+    seg = make_runs(mykey, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
     // more distinct cells than slots: the lanes of the cells beyond go to the general build one by one (handing over the whole
     // wave made 15 % of the population take the slow path by the end of a 16-step interval)
     if (myslot >= SLOTS) {

@@ -85,6 +85,10 @@ struct Redo { int *list; int *count; long long k0, klen; int *lane; int step;   
 // KID_HOT3_SLOTS cell packets and KID_HOT3_CHUNK staging rows.  Measured at 1e7 bergs: 0.98 -> 0.88 ms per launch with 12 + 10;
 // 11 + 11 holds the step's eleven staged values (floating_melt, berg_melt, nine mass_on_ocean slots; the heat-flux plane is
 // staged only by a wave that has heat) in ONE flush instead of two: 0.805 -> 0.777 ms.
+#ifndef KID_FLP_SLOTS
+#define KID_FLP_SLOTS KID_MAXRUN
+#define KID_FLP_CHUNK 10   // (rows 0-9 park the footloose build's values; it stages at most nine: 14.8 KB per wave = 12 LDS blocks, ten waves per CU instead of nine)
+#endif
 #ifndef KID_HOT3_SLOTS
 #define KID_HOT3_SLOTS 11
 #define KID_HOT3_CHUNK 11
@@ -95,11 +99,11 @@ template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg 
 #else
   static constexpr bool three = FAST && RK && OLD_ORDER && (K == 1 || K == 3) && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
 #endif
-  static constexpr int slots = three ? KID_HOT3_SLOTS : KID_MAXRUN;   // cell packets per wave
+  static constexpr int slots = three ? KID_HOT3_SLOTS : ((FAST && K == 2) ? KID_FLP_SLOTS : KID_MAXRUN);   // cell packets per wave
   // a slot per distinct cell, or per run: a sparse population (the footloose profile's 5 bergs per cell: 13 cells per wave, a run
   // each) gains nothing from the search for repeated cells and pays ~2 % for it (measured, config 3)
   static constexpr bool distinct = K != 2;
-  static constexpr int chunk = three ? KID_HOT3_CHUNK : KID_CHUNK;    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
+  static constexpr int chunk = three ? KID_HOT3_CHUNK : ((FAST && K == 2) ? KID_FLP_CHUNK : KID_CHUNK);    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
   static constexpr int waves = !FAST ? KID_GENERAL_WAVES_PER_EU : (three ? 3 : KID_WAVES_PER_EU);
 };
 template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K = 0>

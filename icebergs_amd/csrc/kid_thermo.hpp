@@ -43,7 +43,6 @@ struct Seg {
   lds_int *plane;    // [KID_CHUNK] plane id of staged slot
   unsigned long long heads;  // bit l: lane l starts a run
   int R;             // number of runs in this wave
-  unsigned M;        // ceil(65536 / R): item / R == (item * M) >> 16 for item < 1024
   int npend;         // staged slots (wave-uniform)
   int chunk;         // staged slots per flush (KID_CHUNK; fewer in the builds that trade staging rows for a third wave per SIMD)
 };
@@ -68,7 +67,6 @@ __device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *int
   const unsigned long long heads = __ballot(is_head);
   s.heads = heads;
   s.R = __popcll(heads);
-  s.M = (65536u + (unsigned)s.R - 1u) / (unsigned)s.R;
   if (is_head) {
     const int r = __popcll(heads & ((1ull << lane) - 1ull));
     const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
@@ -86,9 +84,10 @@ __device__ __forceinline__ Seg make_runs(int key, lds_double *vals, lds_int *int
 // added in order ((p0 + p1) + p2) + p3 through two shuffles and the first piece's lane issues the atomic.  Still a fixed
 // order of additions for a given arrangement of the lanes.
 __device__ __noinline__ void seg_flush_impl(lds_double *val, lds_int *head, lds_int *len, lds_int *cell, lds_int *plane,
-                                            int R, unsigned M, int npend, double *acc, size_t ncell) {
+                                            int R, int npend, double *acc, size_t ncell) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int lane = (int)__lane_id();
+  const float rR = __builtin_amdgcn_rcpf((float)R);
   const int nitems = npend * R;
   const int P = (nitems * 4 <= 64) ? 4 : ((nitems * 2 <= 64) ? 2 : 1);   // wave-uniform
   const int lg = (P == 4) ? 2 : ((P == 2) ? 1 : 0);
@@ -96,7 +95,10 @@ __device__ __noinline__ void seg_flush_impl(lds_double *val, lds_int *head, lds_
     const int item = base + (lane >> lg), part = lane & (P - 1);
     const bool live = item < nitems;
     const int it = live ? item : 0;
-    const int q = (int)(((unsigned)it * M) >> 16), r = it - q * R;
+    // item / R and item % R without the 25 instructions of an integer division: the float quotient is within one of the truth
+    // (item < 1024, R <= 64), one correction either way
+    int q = (int)((float)it * rR), r = it - q * R;
+    if (r < 0) { q -= 1; r += R; } else if (r >= R) { q += 1; r -= R; }
     const int h = head[r], n = len[r], c = cell[r];
     const int per = (n + P - 1) >> lg;                 // values per piece
     const int t0 = part * per, t1 = (t0 + per < n) ? t0 + per : n;
@@ -126,7 +128,7 @@ __device__ __noinline__ void seg_flush_impl(lds_double *val, lds_int *head, lds_
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 __device__ __forceinline__ void seg_flush(Seg &s, double *acc, size_t ncell) {
-  if (s.npend > 0) seg_flush_impl(s.val, s.head, s.len, s.cell, s.plane, s.R, s.M, s.npend, acc, ncell);
+  if (s.npend > 0) seg_flush_impl(s.val, s.head, s.len, s.cell, s.plane, s.R, s.npend, acc, ncell);
   s.npend = 0;
 }
 // All lanes of the wave must call this together (every call site is in wave-uniform control flow).

@@ -122,16 +122,21 @@ def other_configs(np, torch, S, T, Icebergs, budget_s=75.0):
         ib = Icebergs(grid, p, capacity=len(b["lon"]), device=torch.cuda.current_device())
         ib.upload_bergs(b)
         ib.set_store_environment(False)   # ignore_traj=T: nobody reads berg%uo..hi back (the fused step interpolates for itself)
+        # one whole re-binning interval is timed, its re-binning included: the kernel slows as the cell order decays between two
+        # of them (1.03 -> 1.3 ms over 16 steps) and the re-binning itself is 3.4 ms at this size.  24 steps between two: measured
+        # 1.39 ms/step against 1.43 at the library's default of 16 (tools/profiling/ab_c3_long.sh)
+        interval = 24
+        ib.set_resort_interval(interval)
         ib.run(3); ib.sync()
         ib.profile(True)
-        steps = 12
+        steps = interval
         t0 = time.perf_counter(); ib.run(steps); ib.sync(); dt = time.perf_counter() - t0
         ms, launches, _ = ib.profile_get(); ib.profile(False)
         n_slots, n_alive = ib.num_bergs()
         kern = ms / steps      # per step: the fused launch + the short launch over the step's new children
         out["c3"] = {"workload": "BASELINE configs[2]: 1e7 bergs, footloose (fl_bits, displaced children), Verlet, 2000x1000 periodic 1 km grid, dt=10 s",
                      "ms_per_step": 1e3 * dt / steps, "berg_steps_per_s": n * steps / dt, "steps": steps, "bergs_alive_at_end": int(n_alive),
-                     "store_environment": False,
+                     "store_environment": False, "rebin_interval": interval,
                      "roofline": {"bound": "hbm", "algorithmic_bytes_per_berg_step": 320, "kernel_ms_per_step": kern, "kernel_launches": int(launches),
                                   "achieved": 320.0 * n / (kern * 1e-3) / 1e9 if kern > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": (320.0 * n / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern > 0 else 0.0}}

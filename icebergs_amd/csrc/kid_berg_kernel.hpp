@@ -100,9 +100,6 @@ template <bool RK, bool OLD_ORDER, unsigned PH, bool FAST, int K> struct HotCfg 
   static constexpr bool three = FAST && RK && OLD_ORDER && (K == 1 || K == 3) && (PH & PH_EVOLVE) != 0 && KID_HOT_WG == 64;
 #endif
   static constexpr int slots = three ? KID_HOT3_SLOTS : ((FAST && K == 2) ? KID_FLP_SLOTS : KID_MAXRUN);   // cell packets per wave
-  // a slot per distinct cell, or per run: a sparse population (the footloose profile's 5 bergs per cell: 13 cells per wave, a run
-  // each) gains nothing from the search for repeated cells and pays ~2 % for it (measured, config 3)
-  static constexpr bool distinct = K != 2;
   static constexpr int chunk = three ? KID_HOT3_CHUNK : ((FAST && K == 2) ? KID_FLP_CHUNK : KID_CHUNK);    // staging rows per wave (>= 7: the rows the plain build parks M .. heat_density in)
   static constexpr int waves = !FAST ? KID_GENERAL_WAVES_PER_EU : (three ? 3 : KID_WAVES_PER_EU);
 };
@@ -185,43 +182,29 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
   double *scal = acc - KID_NSCALAR;   // the step's scalar increments sit in front of plane 0 (kid_accum_device_ptr)
 
   // runs of equal cell among the 64 lanes (the SoA is cell-sorted): shared by the packet staging and the scatter
-  // (hot builds that give a packet slot to every distinct cell find the cells from the lanes' own keys and build the run tables
-  // after the packet loads are on their way; the others need the runs first)
+  // (the hot build finds its packet cells from the lanes' own keys and builds the run tables of the scatter after the packet
+  // loads are on their way)
   const int mykey = was_alive ? g.idx(d.ine, d.jne) : -1;
   Seg seg;
-  if constexpr (!(FAST && Cfg::distinct)) seg = make_runs(mykey, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
+  if constexpr (!FAST) seg = make_runs(mykey, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
   const lds_double *pk = nullptr;
   if (FAST) {
     lds_double *wpk = (lds_double *)lds_pk + (threadIdx.x >> 6) * (SLOTS * PK_STRIDE);
     const int lane = (int)__lane_id();
-    // One packet slot per DISTINCT cell of the wave's runs (Cfg::distinct).  As the cell order decays between two re-binnings a wave collects
+    // One packet slot per DISTINCT cell of the wave's lanes.  As the cell order decays between two re-binnings a wave collects
     // out-of-place bergs, each a run of its own that also splits the run it sits in: a slot per run staged the same packet
     // again and again and ran out of slots two thirds into a 16-step interval (runs ~ 1.5 + 1.3 per step at 139 bergs per
-    // cell), although the bergs of a tile only ever spread over the handful of cells around where they were binned.
+    // cell), although the bergs of a tile only ever spread over the handful of cells around where they were binned.  The sparse
+    // population of the footloose profile (5 bergs per cell, 13 cells per wave when freshly binned) pays ~2 % for the search
+    // while its order is fresh and gains 25 % over a whole interval: a berg that hops to the next cell in i usually lands in a
+    // cell the wave already holds (config 3, 32 steps: 2.02 -> 1.51 ms/step).
     // The packets go from memory straight into LDS (gfx950: global_load_lds_dwordx4, 16 bytes per lane, lane l to LDS base + 16 l):
     // one instruction per cell with the first 34 lanes moves the 544-byte packet, no staging registers, and every cell's load is
     // in flight before the single wait.  The cell of a slot is wave-uniform (a v_readlane): scalar address arithmetic.
     const gchar *gp = (const gchar *)g.pkt;
     static_assert(PK_SIZE * 8 == 34 * 16 && (PK_STRIDE * 8) % 16 == 0 && (PK_GSTRIDE * 8) % 16 == 0, "packet = 34 lanes x 16 bytes, 16-byte aligned slots");
     int myslot;
-    if constexpr (!Cfg::distinct) {   // one slot per run
-    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const int myrun = __popcll(seg.heads & le) - 1;
-    if (myrun >= SLOTS) {
-      if (was_alive) { const int slot = atomicAdd(redo.count, 1); redo.list[slot] = (int)kk; if (redo.lane) redo.lane[kk] = redo.step + 1; }
-      was_alive = false;
-    }
-    const int nstage = seg.R < SLOTS ? seg.R : SLOTS;
-    const int mycell = seg.cell[lane < SLOTS ? lane : 0];
-    const unsigned loff = (unsigned)lane * 16u;
-    for (int u = 0; u < nstage; ++u) {  // wave-uniform
-      const int cu = __builtin_amdgcn_readlane(mycell, u);
-      if (cu >= 0 && lane < 34)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)cu * (size_t)(PK_GSTRIDE * 8) + loff),
-                                         (__attribute__((address_space(3))) void *)(wpk + u * PK_STRIDE), 16, 0, 0);
-    }
-    myslot = myrun < 0 ? 0 : myrun;
-    } else {
+    {
     // every lane knows its own cell: the wave walks over the distinct cells of its live lanes (first lane not yet served, its
     // cell by v_readlane, a ballot of the lanes that share it) -- no table look-up, no shuffle
     const unsigned loff = (unsigned)lane * 16u;

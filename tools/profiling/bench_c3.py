@@ -15,6 +15,7 @@ ib = Icebergs(grid, p, capacity=cap, device=0)
 ib.upload_bergs(b)
 if os.environ.get("KID_C3_NO_ENV_STORE"):   # the fused step does not read the stored environment back: 104 B per berg-step less to write
     ib.set_store_environment(False)
+ib.set_resort_interval(int(sys.argv[3]) if len(sys.argv) > 3 else 24)   # re-binning interval (the library's default is 16; 24 is bench.py's choice for this config)
 ib.run(2); ib.sync()
 t0 = time.time()
 ib.run(steps); ib.sync()

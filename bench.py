@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep the all-reduce and the gather on the critical path")
     ap.add_argument("--split-general", action="store_true", help="experiment: hot build in two halves, general build on the side stream")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the N>1 code path (RCCL all-reduce) with one rank")
-    ap.add_argument("--resort", type=int, default=12, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
+    ap.add_argument("--resort", type=int, default=16, help="re-bin the bergs by cell every this many steps (move_berg_between_cells)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 rehearsal without N GPUs: every rank uses GPU 0 and the exchange goes through gloo (what is exercised is the N>1 code path, not its speed)")
     ap.add_argument("--advance-clock", action="store_true", help="kid_set_params with an advancing current_yearday before every step, as a model run does")
     ap.add_argument("--slow-lane", action="store_true", help="step the bergs the hot build hands over on a second stream for two steps (round 2's default: it paid while the "

@@ -127,6 +127,7 @@ def other_configs(np, torch, S, T, Icebergs, budget_s=75.0):
         # 1.39 ms/step against 1.43 at the library's default of 16 (tools/profiling/ab_c3_long.sh)
         interval = 24
         ib.set_resort_interval(interval)
+        ib.move_berg_between_cells()   # (the first re-binning allocates its 6 GB of double buffers: 0.2 s on some boxes, not part of a step)
         ib.run(3); ib.sync()
         ib.profile(True)
         steps = interval

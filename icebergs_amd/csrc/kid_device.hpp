@@ -41,7 +41,11 @@ __device__ __forceinline__ void kid_tick(int idx, int idx2 = 0) {   // idx < 0: 
     if (idx < 0) { for (int q = 0; q < 16; ++q) tl[w][q] = 0ull; }
     else if (idx == 99) {
       const unsigned long long row = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)w;
-      if ((gridDim.x > 4096u || idx2) && row < (unsigned long long)KID_TPROF_WAVES) {   // (the hot build's launches only: the general build's grid is small; idx2: any grid)
+#ifdef KID_EXP_TIMING_GENERAL   // the general build's launches instead (a grid of at most 2048 waves)
+      if (gridDim.x <= 4096u && row < (unsigned long long)KID_TPROF_WAVES) {
+#else
+      if ((gridDim.x > 4096u || idx2) && row < (unsigned long long)KID_TPROF_WAVES) {
+#endif   // (the hot build's launches only: the general build's grid is small; idx2: any grid)
         unsigned long long *r = kid_tprof + row * 16ull;
         r[0] += 1ull;
         for (int q = 1; q < 16; ++q) r[q] += tl[w][q];
@@ -269,9 +273,36 @@ template <> struct CellOf<true> {
   typedef PkCell type;
   static __device__ __forceinline__ PkCell make(const DevGrid &, const lds_double *pk, int, int) { return PkCell{pk}; }
 };
+// The general build reads the same gathered packet, from memory: one base address and fixed offsets per cell (576 contiguous
+// bytes) instead of three record arrays indexed by neighbour -- its interpolation and cell search were chains of dependent
+// loads (a third of a general-build wave's 83 us, tools/profiling/time_segments.py with KID_EXP_TIMING_GENERAL).  Every cell a
+// berg can sit in has a packet (kid_upload_bergs admits the computational domain and the first halo row; the halo is two
+// cells wide at least); -DKID_EXP_GENERAL_RECORDS keeps the record arrays.
+typedef __attribute__((address_space(1))) double kid_gdouble;
+struct GlbPkCell {
+  const kid_gdouble *pk;
+  __device__ __forceinline__ double vel(int k, int f) const { return pk[PK_VEL + k * 8 + f]; }
+  __device__ __forceinline__ Corners corners() const {
+    return Corners{pk[PK_CORNER + 0], pk[PK_CORNER + 1], pk[PK_CORNER + 2], pk[PK_CORNER + 3],
+                   pk[PK_CORNER + 6], pk[PK_CORNER + 7], pk[PK_CORNER + 4], pk[PK_CORNER + 5]};
+  }
+  __device__ __forceinline__ double t0(int f) const { return pk[PK_T0 + f]; }
+  __device__ __forceinline__ double ddx(int k) const { return pk[PK_DDX + k]; }
+  __device__ __forceinline__ double ddy(int k) const { return pk[PK_DDY + k]; }
+  __device__ __forceinline__ double area() const { return pk[PK_AREA]; }
+  __device__ __forceinline__ double msk(int di, int dj) const { return pk[PK_MSK + (di + 1) + 3 * (dj + 1)]; }
+  __device__ __forceinline__ bool unrot() const { return fabs(pk[PK_HOTOK]) >= 5.; }
+};
 template <> struct CellOf<false> {
+#ifdef KID_EXP_GENERAL_RECORDS
   typedef GlbCell type;
   static __device__ __forceinline__ GlbCell make(const DevGrid &g, const lds_double *, int i, int j) { return GlbCell{g, g.idx(i, j)}; }
+#else
+  typedef GlbPkCell type;
+  static __device__ __forceinline__ GlbPkCell make(const DevGrid &g, const lds_double *, int i, int j) {
+    return GlbPkCell{(const kid_gdouble *)g.pkt + (size_t)g.idx(i, j) * (size_t)PK_GSTRIDE};
+  }
+#endif
 };
 // One wave stages the packet of a cell into LDS: lane q fetches packet element q (and q+64).  Where element q
 // lives (which record array, which neighbour cell, which field) is fixed, so it is resolved once per lane:

@@ -417,6 +417,7 @@ struct kid_handle {
   struct DebugOpts { bool stable_resort = false, no_plain_build = false, fl_unfused = false, new_order_unfused = false, mts_always_label = false, mts_no_fused = false;
                      int mts_fused_blocks_cap = 0, mts_poll_limit = 0; } dbg;
   int32_t *d_iceberg_counter = nullptr;  // grd%iceberg_counter_grd (FW:1017)
+  bool fl_place_warm = false;
   unsigned fl_step = 0;                  // footloose passes so far: third counter word of the child-placement generator (kid_rng.h)
   int *d_fl_cursor = nullptr;
   int32_t *d_fl_head = nullptr, *d_fl_next = nullptr; int64_t *d_fl_newid = nullptr; long long fl_ev_capacity = 0;   // fl_assign_ids_*
@@ -1446,6 +1447,12 @@ static int refresh_tables(kid_handle *h) {
 // reference's loop would have met the events (kid_footloose.hpp, fl_assign_ids_*)
 // second half of calve_fl_icebergs for the children of one pass (kid_footloose.hpp): positions, copied members, constants
 static int fl_place_children(kid_handle *h, long long n_old, int m, unsigned step) {
+  if (!h->fl_place_warm) {   // the kernel's out-of-line helpers need stack scratch, which the runtime allocates at the FIRST launch
+    // (1.6 s at 1e7 bergs' worth of device memory in use): an empty launch at the first footloose pass, not at the first event
+    h->fl_place_warm = true;
+    hipLaunchKernelGGL(fl_place_children_kernel<BergPtrs>, dim3(1), dim3(64), 0, h->stream, dev_grid(h), (const kid_params *)h->d_params, (const BergPtrs *)h->d_bp, n_old, 0, step);
+    KID_HIP(h, hipGetLastError());
+  }
   if (m <= 0) return KID_OK;
   hipLaunchKernelGGL(fl_place_children_kernel<BergPtrs>, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, h->stream, dev_grid(h), (const kid_params *)h->d_params, (const BergPtrs *)h->d_bp, n_old, m, step);
   KID_HIP(h, hipGetLastError());

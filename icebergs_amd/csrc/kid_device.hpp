@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void rolling(const kid_params &p, double &Tn, double 
   const double Dn = q * Tn;
   if (Dn > 0.) {
     if (!Sw<K>::use_updated_rolling_scheme(p) && Sw<K>::tip_parameter(p) < 999.) {          // scheme 3 (default)
-      if (dmax(Wn, Ln) < kid_sqrt(0.92 * (Dn * Dn) + 58.32 * Dn)) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
+      if (dmax(Wn, Ln) < kid_sqrt_nn(0.92 * (Dn * Dn) + 58.32 * Dn)) { swapd(Tn, Wn); if (Wn > Ln) swapd(Wn, Ln); }
     } else {
       if (Wn > Ln) swapd(Ln, Wn);
       if (!Sw<K>::use_updated_rolling_scheme(p) && Sw<K>::tip_parameter(p) >= 999.) {       // scheme 2

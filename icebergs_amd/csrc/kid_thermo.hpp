@@ -221,13 +221,13 @@ __device__ __forceinline__ void thermodynamics(const DevGrid &g, const kid_param
   const double Vol = T * W * L;
   const Rcp rVol = kid_rcp(Vol);
   double du = uvel - e.uo, dv = vvel - e.vo;
-  const double dvo = kid_sqrt(du * du + dv * dv);
+  const double dvo = kid_sqrt_nn(du * du + dv * dv);
   du = e.ua - e.uo; dv = e.va - e.vo;
-  const double dva = kid_sqrt(du * du + dv * dv);
+  const double dva = kid_sqrt_nn(du * du + dv * dv);
 #ifdef KID_EXACT_MATH
   const double Ss = 1.5 * kid_pow(dva, 0.5) + 0.1 * dva;
 #else
-  const double Ss = 1.5 * kid_sqrt(dva) + 0.1 * dva;   // dva**0.5 (IB:2908)
+  const double Ss = 1.5 * kid_sqrt_nn(dva) + 0.1 * dva;   // dva**0.5 (IB:2908)
 #endif
   const double dvo08 = kid_pow08(dvo);
   double Mv = dmax(7.62e-3 * SST + 1.29e-3 * (SST * SST), 0.) * perday;

@@ -185,6 +185,11 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
   // (the hot build finds its packet cells from the lanes' own keys and builds the run tables of the scatter after the packet
   // loads are on their way)
   const int mykey = was_alive ? g.idx(d.ine, d.jne) : -1;
+  // sin / cos of the cell's reference latitude for the first RK4 stage (lat_terms_cell): fetched with the cell packets
+  double latref_s = 0., latref_c = 1.;
+  if constexpr (FAST && RK && (PH & PH_EVOLVE) != 0) {
+    if (grid_latlon<K>(g) && g.latref) { const long long c2 = 2ll * (mykey < 0 ? 0 : mykey); latref_s = ldg(g.latref, c2); latref_c = ldg(g.latref, c2 + 1); }
+  }
   Seg seg;
   if constexpr (!FAST) seg = make_runs(mykey, (lds_double *)lds_vals, (lds_int *)lds_ints, CHUNK);
   const lds_double *pk = nullptr;
@@ -267,7 +272,10 @@ __global__ void KID_NUM_VGPR_ATTR __launch_bounds__(FAST ? KID_HOT_WG : 256, (Ho
     const bool moves = was_alive && (t.static_berg < 0.5);
     if (moves) {
       const BergGeom bg{t.M, t.T, t.W, t.L, t.n_bonds};
-      if (RK) rk4_step<OLD_ORDER, FAST, K>(g, p, bg, e, d, tickets, err, bail, pk);
+      if (RK) {
+        if constexpr (!FAST) { if (grid_latlon<K>(g) && g.latref) { const long long c2 = 2ll * g.idx(d.ine, d.jne); latref_s = ldg(g.latref, c2); latref_c = ldg(g.latref, c2 + 1); } }
+        rk4_step<OLD_ORDER, FAST, K>(g, p, bg, e, d, tickets, err, bail, pk, latref_s, latref_c);
+      }
       else verlet_step<OLD_ORDER, FAST, K>(g, p, bg, e, d, tickets, err, bail, pk);
       if constexpr (PARK) {
         KID_PHASE_FENCE();

@@ -200,6 +200,9 @@ struct DevGrid {
   // forcing change (pack_packets_kernel): the hot build stages a cell with two contiguous loads per lane instead of
   // resolving, per lane, which record of which neighbour cell element q lives in and loading from 64 different records
   const double *pkt;
+  // (sin, cos) of the latitude of every cell's north-east corner (pack_static_kernel): the first RK4 stage gets sin / cos of the
+  // berg's own latitude from them by the angle-addition formulas (lat_terms_cell); null on a Cartesian grid
+  const double *latref;
   // Parameter-only subexpressions of the hot loop, evaluated once on the host with the same IEEE operations (so the
   // results are the ones every lane used to compute for itself, per RK4 stage): sin(pi/180*lat_ref) alone was 7 % of
   // the step
@@ -239,6 +242,7 @@ struct GlbCell {
     const GeoRec a = g.geo[c - g.ni - 1], b = g.geo[c - g.ni], d = g.geo[c], e = g.geo[c - 1];
     return Corners{a.lon, a.lat, b.lon, b.lat, d.lon, d.lat, e.lon, e.lat};
   }
+  __device__ __forceinline__ double corner_lat11() const { return g.geo[c].lat; }
   __device__ __forceinline__ double t0(int f) const { return reinterpret_cast<const double *>(g.trc + c)[f]; }
   // ddx_ssh at (0,+1),(0,0),(0,-1),(-1,+1),(-1,0),(-1,-1); ddy_ssh at (+1,0),(0,0),(-1,0),(+1,-1),(0,-1),(-1,-1)
   __device__ __forceinline__ double ddx(int k) const { return g.trc[c - (k / 3) + (1 - (k % 3)) * g.ni].ddx; }
@@ -256,6 +260,7 @@ struct PkCell {
     return Corners{pk[PK_CORNER + 0], pk[PK_CORNER + 1], pk[PK_CORNER + 2], pk[PK_CORNER + 3],
                    pk[PK_CORNER + 6], pk[PK_CORNER + 7], pk[PK_CORNER + 4], pk[PK_CORNER + 5]};
   }
+  __device__ __forceinline__ double corner_lat11() const { return pk[PK_CORNER + 7]; }
   __device__ __forceinline__ double t0(int f) const { return pk[PK_T0 + f]; }
   __device__ __forceinline__ double ddx(int k) const { return pk[PK_DDX + k]; }
   __device__ __forceinline__ double ddy(int k) const { return pk[PK_DDY + k]; }
@@ -286,6 +291,7 @@ struct GlbPkCell {
     return Corners{pk[PK_CORNER + 0], pk[PK_CORNER + 1], pk[PK_CORNER + 2], pk[PK_CORNER + 3],
                    pk[PK_CORNER + 6], pk[PK_CORNER + 7], pk[PK_CORNER + 4], pk[PK_CORNER + 5]};
   }
+  __device__ __forceinline__ double corner_lat11() const { return pk[PK_CORNER + 7]; }
   __device__ __forceinline__ double t0(int f) const { return pk[PK_T0 + f]; }
   __device__ __forceinline__ double ddx(int k) const { return pk[PK_DDX + k]; }
   __device__ __forceinline__ double ddy(int k) const { return pk[PK_DDY + k]; }
@@ -885,6 +891,35 @@ __device__ __forceinline__ LatTerms lat_terms(const DevGrid &g, const kid_params
   return t;
 }
 
+// The first RK4 stage: the berg sits within one cell of its cell's north-east corner, whose sin / cos are tabulated
+// (DevGrid::latref): sin / cos of lat = lat_c + d from the angle-addition formulas with a 7th / 8th-order Taylor series in d
+// (|d| < 0.02 rad: truncation < 1e-18) -- ~15 instructions instead of a sincos with argument reduction
+// (~120, 6 % of the step's vector instructions).  Both builds use it (the same numbers for a berg whichever build steps
+// it); not bitwise equal to sincos(lat) (differences ~2e-16); -DKID_EXACT_MATH keeps sincos.
+template <int K = 0>
+__device__ __forceinline__ LatTerms lat_terms_cell(const DevGrid &g, const kid_params &p, double lat, double sin_ref,
+                                                   double lat_c, double s_c, double c_c, bool have_ref) {
+#ifdef KID_EXACT_MATH
+  (void)lat_c; (void)s_c; (void)c_c; (void)have_ref;
+  return lat_terms<K>(g, p, lat, sin_ref);
+#else
+  LatTerms t;
+  if (!grid_latlon<K>(g)) { t.dxdl = 1.; t.sin_f = sin_ref; t.s = 0.; t.c = 1.; return t; }
+  const double d = (lat - lat_c) * g.pi_180;
+  double s, c;
+  if (have_ref && fabs(d) < 0.02) {   // (1.15 degrees: the next terms of the two series are < 1e-18 there; taller cells take sincos)
+    const double d2 = d * d;   // Horner with fused multiply-adds: sin d = d + d^3 (-1/6 + d^2 (1/120 - d^2/5040)), cos d = 1 + d^2 (-1/2 + d^2 (1/24 + d^2 (-1/720 + d^2/40320)))
+    const double sd = kid_fma(d * d2, kid_fma(d2, kid_fma(d2, -1. / 5040., 1. / 120.), -1. / 6.), d);
+    const double cd = kid_fma(d2, kid_fma(d2, kid_fma(d2, kid_fma(d2, 1. / 40320., -1. / 720.), 1. / 24.), -0.5), 1.);
+    s = kid_fma(s_c, cd, c_c * sd); c = kid_fma(c_c, cd, -(s_c * sd));
+  } else sincos(lat * g.pi_180, &s, &c);
+  t.dxdl = g.r180_pi * kid_rcp(p.Rearth * c);
+  t.sin_f = Sw<K>::use_f_plane(p) ? sin_ref : s;
+  t.s = s; t.c = c;
+  return t;
+#endif
+}
+
 // RK4 stages 2-4 sit within a few hundred metres of stage 1: sin/cos of lat1 + d come from the angle-addition formulas
 // with a 5th/4th-order Taylor series in d (|d| < 2e-3 rad: truncation < 1e-17), ~20 instructions instead of a sincos
 // with argument reduction (~150).  Not bitwise equal to sincos(lat) (differences ~1e-16); -DKID_EXACT_MATH keeps sincos.
@@ -900,10 +935,10 @@ __device__ __forceinline__ LatTerms lat_terms_near(const DevGrid &g, const kid_p
   const double d = (lat - lat1) * g.pi_180;
   double s, c;
   if (fabs(d) < 2.e-3) {
-    const double d2 = d * d;
-    const double sd = d * (1. - d2 * (1. / 6.) * (1. - d2 * (1. / 20.)));
-    const double cd = 1. - d2 * 0.5 * (1. - d2 * (1. / 12.));
-    s = s1 * cd + c1 * sd; c = c1 * cd - s1 * sd;
+    const double d2 = d * d;   // sin d = d + d^3 (-1/6 + d^2/120), cos d = 1 + d^2 (-1/2 + d^2/24), Horner with fused multiply-adds
+    const double sd = kid_fma(d * d2, kid_fma(d2, 1. / 120., -1. / 6.), d);
+    const double cd = kid_fma(d2, kid_fma(d2, 1. / 24., -0.5), 1.);
+    s = kid_fma(s1, cd, c1 * sd); c = kid_fma(c1, cd, -(s1 * sd));
   } else sincos(lat * g.pi_180, &s, &c);
   t.dxdl = g.r180_pi * kid_rcp(p.Rearth * c);
   t.sin_f = Sw<K>::use_f_plane(p) ? sin_ref : s;
@@ -941,7 +976,8 @@ struct BergDyn {
 // ---------------------------------------------------------------------------------------------------------
 template <bool OLD_ORDER, bool FAST, int K = 0>
 __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, const BergGeom &bg, const Env &stored,
-                                         BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk) {
+                                         BergDyn &d, unsigned &tickets, int &err, bool &bail, const lds_double *pk,
+                                         double latref_s = 0., double latref_c = 1.) {
   const double dt = p.dt, dt_2 = 0.5 * dt, dt_6 = dt / 6.;
   const double sin_ref = g.sin_lat_ref;
   const double dydl = grid_latlon<K>(g) ? g.dydl : 1.;
@@ -993,7 +1029,11 @@ __device__ __forceinline__ void rk4_step(const DevGrid &g, const kid_params &p, 
     KID_PHASE_FENCE();
     KID_MARK("after_adjust"); KID_TICK(1);
     LatTerms lt;
-    if (s == 0) { lt = lat_terms<K>(g, p, lat_s, sin_ref); s_lat1 = lt.s; c_lat1 = lt.c; }
+    if (s == 0) {   // (the cell's reference: the latitude of its north-east corner from the packet, its sin / cos from DevGrid::latref)
+      const typename CellOf<FAST>::type c0 = CellOf<FAST>::make(g, pk, i1, j1);
+      lt = lat_terms_cell<K>(g, p, lat_s, sin_ref, c0.corner_lat11(), latref_s, latref_c, g.latref != nullptr);
+      s_lat1 = lt.s; c_lat1 = lt.c;
+    }
     else lt = lat_terms_near<K>(g, p, lat_s, sin_ref, lat1, s_lat1, c_lat1);
     double qu = uvel_s * lt.dxdl, qv = vvel_s * dydl;          // u_k, v_k  IB:7412
     KID_PHASE_FENCE();

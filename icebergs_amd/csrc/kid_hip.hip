@@ -38,12 +38,13 @@ namespace {
 // -------------------------------------------------------------------------------------------------------
 struct GridPlanes { const double *st[KID_NGRID_STATIC]; const double *fo[KID_NFORCING]; };
 
-__global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec *geo, double *hotok, int ni, int nj, int latlon, double Lx) {
+__global__ void __launch_bounds__(256) pack_static_kernel(GridPlanes gp, GeoRec *geo, double *hotok, double *latref, double pi_180, int ni, int nj, int latlon, double Lx) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ni * nj) return;
   GeoRec r;
   r.lon = gp.st[KID_G_LON][c]; r.lat = gp.st[KID_G_LAT][c]; r.area = gp.st[KID_G_AREA][c]; r.msk = gp.st[KID_G_MSK][c];
   geo[c] = r;
+  if (latref) { double s_, c_; sincos(r.lat * pi_180, &s_, &c_); latref[2 * c] = s_; latref[2 * c + 1] = c_; }   // DevGrid::latref
   // DevGrid::hotok: may the hot build step a berg of this cell?  Its in-cell test is "(xi, yj) inside the unit square",
   // which is the reference's point-in-cell test (FW:6076-6160) exactly when the four corners form a strictly convex
   // quadrilateral (the bilinear map of calc_xiyj is then one-to-one onto it); polar cells (FW:6359) and cells whose
@@ -376,7 +377,7 @@ struct kid_handle {
   int64_t capacity = 0, n = 0;
   // device memory
   double *d_static[KID_NGRID_STATIC] = {}, *d_forcing[KID_NFORCING] = {};
-  VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr; double *d_hotok = nullptr;
+  VelRec *d_vel = nullptr; TrcRec *d_trc = nullptr; GeoRec *d_geo = nullptr; double *d_hotok = nullptr; double *d_latref = nullptr;
   // the accumulator block: KID_NSCALAR step scalars, then KID_NACC planes of ncell (scalars first, so that they and the planes a
   // step really fills -- a prefix -- are ONE contiguous range for the all-reduce); d_acc points at plane 0
   double *d_acc_own = nullptr, *d_acc = nullptr;
@@ -475,7 +476,7 @@ static DevGrid dev_grid(const kid_handle *h) {
   g.isd = h->gd.isd; g.ied = h->gd.ied; g.jsd = h->gd.jsd; g.jed = h->gd.jed;
   g.isc = h->gd.isc; g.iec = h->gd.iec; g.jsc = h->gd.jsc; g.jec = h->gd.jec;
   g.ni = h->ni; g.nj = h->nj; g.latlon = h->gd.grid_is_latlon; g.regular = h->gd.grid_is_regular; g.Lx = h->gd.Lx;
-  g.vel = h->forc_parity ? h->d_vel2 : h->d_vel; g.trc = h->forc_parity ? h->d_trc2 : h->d_trc; g.geo = h->d_geo; g.hotok = h->d_hotok;
+  g.vel = h->forc_parity ? h->d_vel2 : h->d_vel; g.trc = h->forc_parity ? h->d_trc2 : h->d_trc; g.geo = h->d_geo; g.hotok = h->d_hotok; g.latref = h->d_latref;
   g.pkt = h->d_pkt[h->forc_parity ? 1 : 0];
   g.dx = h->d_static[KID_G_DX]; g.dy = h->d_static[KID_G_DY]; g.ocean_depth = h->d_static[KID_G_OCEAN_DEPTH];
   g.ssh = h->d_forcing[KID_F_SSH];
@@ -609,6 +610,7 @@ int kid_create(const kid_grid_desc *grid, const kid_params *params, int64_t capa
   KID_HIP(h, hipMalloc(&h->d_geo, h->ncell * sizeof(GeoRec)));
   KID_HIP(h, hipMalloc(&h->d_hotok, h->ncell * sizeof(double)));
   KID_HIP(h, hipMemset(h->d_hotok, 0, h->ncell * sizeof(double)));
+  if (grid->grid_is_latlon) KID_HIP(h, hipMalloc(&h->d_latref, 2 * h->ncell * sizeof(double)));   // DevGrid::latref
   const size_t accn = (size_t)KID_NACC * h->ncell + KID_NSCALAR;
   KID_HIP(h, hipMalloc(&h->d_acc_own, accn * sizeof(double)));
   KID_HIP(h, hipMemset(h->d_acc_own, 0, accn * sizeof(double)));
@@ -670,6 +672,7 @@ int kid_destroy(kid_handle *h) {
   if (h->d_trc) (void)hipFree(h->d_trc);
   if (h->d_geo) (void)hipFree(h->d_geo);
   if (h->d_hotok) (void)hipFree(h->d_hotok);
+  if (h->d_latref) (void)hipFree(h->d_latref);
   if (h->d_keep) (void)hipFree(h->d_keep);
   if (h->d_acc_own) (void)hipFree(h->d_acc_own);
   if (h->d_out) (void)hipFree(h->d_out);
@@ -827,7 +830,7 @@ static int pack_static(kid_handle *h) {
   for (int k = 0; k < KID_NGRID_STATIC; ++k) gp.st[k] = h->d_static[k];
   for (int k = 0; k < KID_NFORCING; ++k) gp.fo[k] = h->d_forcing[k];
   const int nb = (int)((h->ncell + 255) / 256);
-  hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, h->d_hotok, h->ni, h->nj, (int)h->gd.grid_is_latlon, h->gd.Lx);
+  hipLaunchKernelGGL(pack_static_kernel, dim3(nb), dim3(256), 0, h->stream, gp, h->d_geo, h->d_hotok, h->d_latref, h->params.pi / 180., h->ni, h->nj, (int)h->gd.grid_is_latlon, h->gd.Lx);
   KID_HIP(h, hipGetLastError());
   return h->have_forcing ? pack_packets(h) : KID_OK;   // (the other parity's packets are rebuilt by the pack_forcing that precedes their use)
 }

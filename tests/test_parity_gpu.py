@@ -712,3 +712,28 @@ def test_periodic_seams(oracle):
     b = S.place_bergs(grid, 400, 33, (1, 20), (4, 17), klass=np.arange(400) % 10)
     ref, got = _both(grid, p, b, 60, "fused")
     P.compare(ref, got, "seam/cartesian", params=p)
+
+
+def test_accum_live_count_is_what_the_python_host_reduces():
+    """kid_accum_live_count (what a Fortran / MPI host sums across ranks) and accumulator_views (what
+    the RCCL path of bench.py sums) name the same prefix of the accumulator block, whatever the namelist asks for"""
+    from icebergs_amd.framework import Icebergs
+    from icebergs_amd.distributed import accumulator_views
+    from icebergs_amd import types as T
+    grid, p0, b = S.config_c2(n=2000, seed=3)
+    E = T.ENUMS
+    cases = [dict(), dict(pass_fields_to_ocean_model=1), dict(diag_mask=E["KID_DIAG_SPREAD_AREA"]), dict(diag_mask=E["KID_DIAG_MELT_BUOY"]),
+             dict(diag_mask=E["KID_DIAG_MASS"] | E["KID_DIAG_USTAR_ICEBERG"])]
+    for kw in cases:
+        p = S.params_copy(p0)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        ib = Icebergs(grid, p, capacity=len(b["lon"]), device=0)
+        try:
+            _, count = ib.accum_device_ptr()
+            assert count == T.NSCALAR + T.NACC * ib.ncell
+            live = ib.accum_live_count()
+            want = len(accumulator_views(np.zeros(count), ib.ncell, p.diag_mask, p)[0])
+            assert live == want, (kw, live, want)
+        finally:
+            ib.close()

@@ -31,6 +31,15 @@
 
 using namespace kid;
 
+// the plain hot build of the fused RK4 step: its own translation unit in the product build (kid_hot_plain.hip, another machine
+// scheduler), included here in a one-file build
+#ifdef KID_HOT_PLAIN_SEPARATE
+namespace kid { int launch_hot_plain(int K, unsigned nblocks, void *stream, const DevGrid *gtab, const kid_params *pp, const void *bp, long long n, double *acc,
+                                     size_t ncell, const void *flags, const void *redo); }
+#else
+#include "kid_hot_plain.inc"
+#endif
+
 namespace {
 
 // -------------------------------------------------------------------------------------------------------
@@ -1295,10 +1304,8 @@ static int launch_berg(kid_handle *h, long long range_k0 = 0, long long range_le
     }
 #define KID_LAUNCH(RKV, OLDV)                                                                                                   \
   do {                                                                                                                          \
-    if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain && !h->flags.store_env)                                \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
-    else if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                  \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV) ? 3 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
+    if (PH == (PH_EVOLVE | PH_THERMO | PH_SPREAD) && RKV && OLDV && plain)                                                       \
+      (void)kid::launch_hot_plain(h->flags.store_env ? 3 : 1, nbp, (void *)h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, &h->flags, &redo);  \
     else if (PH == (PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD) && !RKV && !OLDV && flprof)                           \
       hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (PH == (PH_INTERP | PH_EVOLVE | PH_FL | PH_THERMO | PH_SPREAD) && !RKV && !OLDV) ? 2 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, h->stream, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, redo);  \
     else                                                                                                                        \
@@ -1369,10 +1376,8 @@ static int launch_berg_lanes(kid_handle *h) {
     /* recorded even without a carry-over launch: everything enqueued on the side stream so far (the gather of the step  \
        before last included) is complete once the next prepass has waited for it */                                          \
     (void)hipEventRecord(h->evC, S); h->evC_live = true;                                                                        \
-    if (RKV && OLDV && plain && !h->flags.store_env)                                                                            \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 1 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
-    else if (RKV && OLDV && plain)                                                                                              \
-      hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true, (RKV && OLDV) ? 3 : 0>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
+    if (RKV && OLDV && plain)                                                                                                   \
+      (void)kid::launch_hot_plain(h->flags.store_env ? 3 : 1, nbp, (void *)M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, &h->flags, &hot); \
     else                                                                                                                        \
     hipLaunchKernelGGL((berg_kernel<RKV, OLDV, PH, true>), dim3(nbp), dim3(KID_HOT_WG), 0, M, gtab, h->d_params, h->d_bp, (long long)h->n, h->d_acc, h->ncell, h->flags, hot); \
     (void)hipEventRecord(evF, M);                                                                                               \

@@ -690,3 +690,46 @@ def test_fortran_two_handles_summed_by_hand(oracle, tmp_path):
         gv = np.concatenate([ranks[0][name], ranks[1][name]])[go]
         rv = bergs[name][alive][ro]
         assert np.allclose(gv, rv, rtol=1e-10, atol=1e-12), (name, float(np.abs(gv - rv).max()))
+
+
+@pytest.mark.gpu
+def test_icebergs_init_derived_parameters(tmp_path):
+    """What ice_bergs_framework_init derives from the namelist, through kid_icebergs_init: the MTS sub-step count from the spring
+    constant (FW:1296-1301: ceiling(dt / (0.3 / sqrt(spring_coef)))), contact_cells_lon / lat from contact_distance on the grid
+    (FW:1492-1519), contact_spring_coef defaulting to spring_coef (FW:1313), Verlet forced by mts (FW:1305-1308), the halo raised
+    for rotating bonded bergs (FW:1243-1246), the scaled fracture thresholds (FW:1355-1356), explicit_inner_mts forced by dem
+    (FW:1436), old_interp_flds_order off with mts (FW:1483)."""
+    gni, gnj, gridres = 20, 20, 1000.0
+    nml = """&icebergs_nml
+  grid_is_latlon = .false.
+  Lx = -1.
+  halo = 1
+  mts = .true.
+  dem = .true.
+  mts_sub_steps = -1
+  spring_coef = 1.e-4
+  iceberg_bonds_on = .true.
+  interactive_icebergs_on = .true.
+  max_bonds = 4
+  contact_distance = 2500.
+  frac_thres_scaling = 2.5
+  frac_thres_n = 4.
+  frac_thres_t = 8.
+  fracture_criterion = 'stress'
+  Runge_not_Verlet = .true.
+  set_melt_rates_to_zero = .true.
+/
+"""
+    (tmp_path / "input.nml").write_text(nml)
+    case, res = str(tmp_path / "init.bin"), str(tmp_path / "init.out")
+    write_init_case(case, gni, gnj, False, 0, gridres, 1800.0, 0.0, -1.0, 64, S.empty_bergs(0), [])
+    r = subprocess.run([INIT, case, res], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    d, fp, st, gb, bonds = read_init_result(res)
+    assert fp.mts == 1 and fp.dem == 1 and fp.Runge_not_Verlet == 0 and fp.old_interp_flds_order == 0 and fp.explicit_inner_mts == 1
+    assert fp.mts_sub_steps == int(np.ceil(1800.0 / (0.3 / np.sqrt(1.0e-4)))) == 60
+    assert fp.contact_spring_coef == fp.spring_coef == 1.0e-4
+    assert fp.contact_cells_lon == 3 and fp.contact_cells_lat == 3          # 2500 m on 1 km cells
+    assert fp.max_bonds == 4 and fp.iceberg_bonds_on == 1 and fp.fracture_criterion_stress == 1
+    assert fp.frac_thres_n == 10.0 and fp.frac_thres_t == 20.0
+    assert (d.isd, d.ied) == (-2, 23)                                        # halo 1 -> 3: rotate_icebergs_for_mass_spreading with bonds
